@@ -1,0 +1,592 @@
+// C ABI of libcaster_hip (see include/caster_hip.h).  Host side only: argument
+// checks, scene flattening into device arrays, scratch slabs, kernel launches.
+#include "caster_hip.h"
+#include "caster_launch.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(CASTER_HIP_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct caster_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // scene
+    bool has_scene = false;
+    caster::SceneDev scene{};
+    std::vector<void*> scene_allocs;
+    // scratch
+    float4* slabs = nullptr;
+    size_t slab_bytes = 0;
+    unsigned long long* rays_dev = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool render_pending = false;
+    int chunk = 0;  // samples per work unit; 0 = automatic
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+void free_scene(caster_hip_ctx* ctx)
+{
+    for (void* p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->scene = caster::SceneDev{};
+    ctx->has_scene = false;
+}
+
+template <typename T>
+int upload_array(caster_hip_ctx* ctx, const std::vector<T>& host, const T** dev_out)
+{
+    *dev_out = nullptr;
+    if (host.empty()) return CASTER_HIP_OK;
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, host.size() * sizeof(T)));
+    ctx->scene_allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = static_cast<const T*>(d);
+    return CASTER_HIP_OK;
+}
+
+// RAII device buffer for the array-at-a-time test entry points.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    hipError_t put(const void* src, size_t bytes)
+    {
+        hipError_t e = alloc(bytes);
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    }
+    hipError_t get(void* dst, size_t bytes) const
+    {
+        return bytes ? hipMemcpy(dst, p, bytes, hipMemcpyDeviceToHost) : hipSuccess;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+caster::CamRec cam_rec(const caster_camera* c)
+{
+    caster::CamRec r;
+    static_assert(sizeof(caster::CamRec) == sizeof(caster_camera), "camera layout");
+    memcpy(&r, c, sizeof r);
+    return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* caster_hip_last_error(void) { return g_err; }
+
+int caster_hip_device_count(int* count)
+{
+    if (!count) return fail(CASTER_HIP_ERR_ARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(CASTER_HIP_ERR_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_create(int device, caster_hip_ctx** out)
+{
+    if (!out) return fail(CASTER_HIP_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(CASTER_HIP_ERR_DEVICE, "no HIP device available (%s); libcaster_hip has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return fail(CASTER_HIP_ERR_ARG, "device %d out of range [0, %d)", device, n);
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(CASTER_HIP_ERR_DEVICE, "hipSetDevice(%d) failed", device);
+    caster_hip_ctx* ctx = new (std::nothrow) caster_hip_ctx();
+    if (!ctx) return fail(CASTER_HIP_ERR_ARG, "out of host memory");
+    ctx->device = device;
+    const char* env_chunk = getenv("CASTER_HIP_CHUNK");
+    if (env_chunk) ctx->chunk = atoi(env_chunk);
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->rays_dev), sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->rays_dev, 0, sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        caster_hip_destroy(ctx);
+        return fail(CASTER_HIP_ERR_DEVICE, "context allocation on device %d failed", device);
+    }
+    *out = ctx;
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_destroy(caster_hip_ctx* ctx)
+{
+    if (!ctx) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    if (ctx->slabs) (void)hipFree(ctx->slabs);
+    if (ctx->rays_dev) (void)hipFree(ctx->rays_dev);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_set_stream(caster_hip_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return fail(CASTER_HIP_ERR_ARG, "ctx is NULL");
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_set_chunk(caster_hip_ctx* ctx, int samples_per_unit)
+{
+    if (!ctx) return fail(CASTER_HIP_ERR_ARG, "ctx is NULL");
+    if (samples_per_unit < 0) return fail(CASTER_HIP_ERR_ARG, "samples_per_unit must be >= 0");
+    ctx->chunk = samples_per_unit;
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_object* objects,
+                            int n_materials, const caster_material* materials,
+                            int n_images, const caster_image* images)
+{
+    if (!ctx) return fail(CASTER_HIP_ERR_ARG, "ctx is NULL");
+    if (n_objects < 0 || n_materials < 0 || n_images < 0) return fail(CASTER_HIP_ERR_ARG, "negative count");
+    if ((n_objects && !objects) || (n_materials && !materials) || (n_images && !images))
+        return fail(CASTER_HIP_ERR_ARG, "NULL table with non-zero count");
+
+    std::vector<float4> sph, rect_a, rect_b;
+    std::vector<int2> sph_meta, rect_meta;
+    for (int k = 0; k < n_objects; ++k) {
+        const caster_object& o = objects[k];
+        if (o.material < 0 || o.material >= n_materials)
+            return fail(CASTER_HIP_ERR_ARG, "object %d: material %d out of range [0, %d)", k, o.material, n_materials);
+        if (o.type == CASTER_HTYPE_SPHERE) {
+            sph.push_back(make_float4(o.g[0], o.g[1], o.g[2], o.g[3]));
+            sph_meta.push_back(make_int2(k, o.material));
+        } else if (o.type == CASTER_HTYPE_RECT_XY) {
+            rect_a.push_back(make_float4(o.g[0], o.g[1], o.g[2], o.g[3]));
+            rect_b.push_back(make_float4(o.g[4], 0.f, 0.f, 0.f));
+            rect_meta.push_back(make_int2(k, o.material));
+        } else {
+            return fail(CASTER_HIP_ERR_ARG, "object %d: unsupported type tag %d", k, o.type);
+        }
+    }
+    for (int k = 0; k < n_materials; ++k) {
+        const caster_material& m = materials[k];
+        if (m.type < 0 || m.type > CASTER_MTYPE_DIFF_LIGHT)
+            return fail(CASTER_HIP_ERR_ARG, "material %d: unknown type tag %d", k, m.type);
+        if (m.tex_type == CASTER_TTYPE_IMAGE_ALBEDO && (m.image < 0 || m.image >= n_images))
+            return fail(CASTER_HIP_ERR_ARG, "material %d: image %d out of range [0, %d)", k, m.image, n_images);
+    }
+    for (int k = 0; k < n_images; ++k) {
+        if (!images[k].data || images[k].w == 0 || images[k].h == 0 || images[k].bpp < 3)
+            return fail(CASTER_HIP_ERR_ARG, "image %d: needs data, non-zero size and bpp >= 3", k);
+    }
+
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+
+    std::vector<caster::MatRec> mats(n_materials);
+    static_assert(sizeof(caster::MatRec) == sizeof(caster_material), "material layout");
+    if (n_materials) memcpy(mats.data(), materials, sizeof(caster_material) * (size_t)n_materials);
+
+    std::vector<caster::ImgRec> imgs(n_images);
+    for (int k = 0; k < n_images; ++k) {
+        const size_t bytes = (size_t)images[k].w * images[k].h * images[k].bpp;
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes));
+        ctx->scene_allocs.push_back(d);
+        HIP_TRY(hipMemcpy(d, images[k].data, bytes, hipMemcpyHostToDevice));
+        imgs[k].data = static_cast<const uint8_t*>(d);
+        imgs[k].w = images[k].w; imgs[k].h = images[k].h; imgs[k].bpp = images[k].bpp; imgs[k].pad = 0;
+    }
+
+    caster::SceneDev& s = ctx->scene;
+    int rc;
+    if ((rc = upload_array(ctx, sph, &s.sph))) return rc;
+    if ((rc = upload_array(ctx, sph_meta, &s.sph_meta))) return rc;
+    if ((rc = upload_array(ctx, rect_a, &s.rect_a))) return rc;
+    if ((rc = upload_array(ctx, rect_b, &s.rect_b))) return rc;
+    if ((rc = upload_array(ctx, rect_meta, &s.rect_meta))) return rc;
+    if ((rc = upload_array(ctx, mats, &s.mats))) return rc;
+    if ((rc = upload_array(ctx, imgs, &s.imgs))) return rc;
+    s.n_sph = (int)sph.size();
+    s.n_rect = (int)rect_a.size();
+    s.n_mat = n_materials;
+    s.n_img = n_images;
+    ctx->has_scene = true;
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_malloc(caster_hip_ctx* ctx, size_t bytes, void** dev_ptr)
+{
+    if (!ctx || !dev_ptr) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_free(caster_hip_ctx* ctx, void* dev_ptr)
+{
+    if (!ctx) return fail(CASTER_HIP_ERR_ARG, "ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipFree(dev_ptr));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_memset_zero(caster_hip_ctx* ctx, void* dev_ptr, size_t bytes)
+{
+    if (!ctx || !dev_ptr) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipMemsetAsync(dev_ptr, 0, bytes, ctx->stream));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_download(caster_hip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes)
+{
+    if (!ctx || !host_dst || !dev_src) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_upload(caster_hip_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes)
+{
+    if (!ctx || !dev_dst || !host_src) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_synchronize(caster_hip_ctx* ctx)
+{
+    if (!ctx) return fail(CASTER_HIP_ERR_ARG, "ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height,
+                      int sample_begin, int sample_count, int max_depth,
+                      uint32_t seed, uint32_t flags, float* accum_dev)
+{
+    if (!ctx || !cam || !accum_dev) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "render before caster_hip_upload_scene");
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
+        return fail(CASTER_HIP_ERR_ARG, "frame size %dx%d out of range", width, height);
+    if (sample_begin < 0 || sample_count < 0) return fail(CASTER_HIP_ERR_ARG, "negative sample range");
+    if ((flags & ~(uint32_t)CASTER_HIP_STRICT) != 0) return fail(CASTER_HIP_ERR_ARG, "unknown flag bits 0x%x", flags);
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipMemsetAsync(ctx->rays_dev, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    ctx->render_pending = true;
+    if (sample_count == 0) {
+        HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+        return CASTER_HIP_OK;
+    }
+
+    int chunk = ctx->chunk > 0 ? ctx->chunk : 64;
+    if (chunk > sample_count) chunk = sample_count;
+    const int n_chunks = (sample_count + chunk - 1) / chunk;
+    const size_t n_pixels = (size_t)width * height;
+    const size_t need = n_pixels * sizeof(float4) * (size_t)n_chunks;
+    if (need > ctx->slab_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->slabs) HIP_TRY(hipFree(ctx->slabs));
+        ctx->slabs = nullptr;
+        ctx->slab_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->slabs), need));
+        ctx->slab_bytes = need;
+    }
+
+    caster::RenderArgs a;
+    a.cam = cam_rec(cam);
+    a.scene = ctx->scene;
+    a.width = width; a.height = height;
+    a.s_begin = sample_begin; a.s_count = sample_count;
+    a.chunk = chunk; a.n_chunks = n_chunks;
+    a.max_depth = max_depth;
+    a.seed = seed;
+    a.slabs = ctx->slabs;
+    a.rays = ctx->rays_dev;
+    if (flags & CASTER_HIP_STRICT) HIP_TRY(caster::launch_render_strict(a, ctx->stream));
+    else HIP_TRY(caster::launch_render_fast(a, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(caster::launch_combine(ctx->slabs, n_chunks, (int)n_pixels, reinterpret_cast<float4*>(accum_dev),
+                                   ctx->stream));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_render_stats(caster_hip_ctx* ctx, uint64_t* rays, float* kernel_ms)
+{
+    if (!ctx) return fail(CASTER_HIP_ERR_ARG, "ctx is NULL");
+    if (!ctx->render_pending) return fail(CASTER_HIP_ERR_STATE, "no render has been issued on this context");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (rays) {
+        unsigned long long r = 0;
+        HIP_TRY(hipMemcpy(&r, ctx->rays_dev, sizeof r, hipMemcpyDeviceToHost));
+        *rays = (uint64_t)r;
+    }
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_resolve_dev(caster_hip_ctx* ctx, const float* accum_dev, int width, int height,
+                           int spp, uint8_t* rgba_dev)
+{
+    if (!ctx || !accum_dev || !rgba_dev) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (width <= 0 || height <= 0 || height > 65535) return fail(CASTER_HIP_ERR_ARG, "bad frame size");
+    if (spp <= 0) return fail(CASTER_HIP_ERR_ARG, "spp must be positive");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(caster::launch_resolve(reinterpret_cast<const float4*>(accum_dev), width, height, spp, rgba_dev,
+                                   ctx->stream));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_resolve(caster_hip_ctx* ctx, const float* accum_dev, int width, int height,
+                       int spp, uint8_t* rgba_host)
+{
+    if (!ctx || !accum_dev || !rgba_host) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (width <= 0 || height <= 0) return fail(CASTER_HIP_ERR_ARG, "bad frame size");
+    DeviceGuard guard(ctx->device);
+    const size_t bytes = (size_t)width * height * 4;
+    DevBuf tmp;
+    HIP_TRY(tmp.alloc(bytes));
+    int rc = caster_hip_resolve_dev(ctx, accum_dev, width, height, spp, tmp.as<uint8_t>());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(rgba_host, tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return CASTER_HIP_OK;
+}
+
+// ---------------------------------------------------- per-function entry points
+#define PICK(flags, base) (((flags) & CASTER_HIP_STRICT) ? caster::base##strict : caster::base##fast)
+
+int caster_hip_test_hit_sphere(caster_hip_ctx* ctx, uint32_t flags, int n,
+                               const float* sph4, const float* ray6, const float* trange2,
+                               int32_t* hit, float* t, float* p3, float* n3, int32_t* face)
+{
+    if (!ctx || !sph4 || !ray6 || !trange2 || !hit || !t || !p3 || !n3 || !face)
+        return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf ds, dr, dt, dhit, dtt, dp, dn, df;
+    HIP_TRY(ds.put(sph4, sizeof(float) * 4 * n));
+    HIP_TRY(dr.put(ray6, sizeof(float) * 6 * n));
+    HIP_TRY(dt.put(trange2, sizeof(float) * 2 * n));
+    HIP_TRY(dhit.alloc(sizeof(int32_t) * n));
+    HIP_TRY(dtt.alloc(sizeof(float) * n));
+    HIP_TRY(dp.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(dn.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(df.alloc(sizeof(int32_t) * n));
+    HIP_TRY(PICK(flags, launch_test_hit_sphere_)(n, ds.as<float>(), dr.as<float>(), dt.as<float>(),
+                                                 dhit.as<int32_t>(), dtt.as<float>(), dp.as<float>(),
+                                                 dn.as<float>(), df.as<int32_t>(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dhit.get(hit, sizeof(int32_t) * n));
+    HIP_TRY(dtt.get(t, sizeof(float) * n));
+    HIP_TRY(dp.get(p3, sizeof(float) * 3 * n));
+    HIP_TRY(dn.get(n3, sizeof(float) * 3 * n));
+    HIP_TRY(df.get(face, sizeof(int32_t) * n));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_test_hit_xy_rect(caster_hip_ctx* ctx, uint32_t flags, int n,
+                                const float* rect5, const float* ray6, const float* trange2,
+                                int32_t* hit, float* t, float* p3, float* n3, int32_t* face, float* uv2)
+{
+    if (!ctx || !rect5 || !ray6 || !trange2 || !hit || !t || !p3 || !n3 || !face || !uv2)
+        return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf ds, dr, dt, dhit, dtt, dp, dn, df, duv;
+    HIP_TRY(ds.put(rect5, sizeof(float) * 5 * n));
+    HIP_TRY(dr.put(ray6, sizeof(float) * 6 * n));
+    HIP_TRY(dt.put(trange2, sizeof(float) * 2 * n));
+    HIP_TRY(dhit.alloc(sizeof(int32_t) * n));
+    HIP_TRY(dtt.alloc(sizeof(float) * n));
+    HIP_TRY(dp.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(dn.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(df.alloc(sizeof(int32_t) * n));
+    HIP_TRY(duv.alloc(sizeof(float) * 2 * n));
+    HIP_TRY(PICK(flags, launch_test_hit_rect_)(n, ds.as<float>(), dr.as<float>(), dt.as<float>(),
+                                               dhit.as<int32_t>(), dtt.as<float>(), dp.as<float>(),
+                                               dn.as<float>(), df.as<int32_t>(), duv.as<float>(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dhit.get(hit, sizeof(int32_t) * n));
+    HIP_TRY(dtt.get(t, sizeof(float) * n));
+    HIP_TRY(dp.get(p3, sizeof(float) * 3 * n));
+    HIP_TRY(dn.get(n3, sizeof(float) * 3 * n));
+    HIP_TRY(df.get(face, sizeof(int32_t) * n));
+    HIP_TRY(duv.get(uv2, sizeof(float) * 2 * n));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_test_hit_list(caster_hip_ctx* ctx, uint32_t flags, int n, const float* ray6,
+                             int32_t* hit, float* t, float* p3, float* n3, int32_t* face, int32_t* mat)
+{
+    if (!ctx || !ray6 || !hit || !t || !p3 || !n3 || !face || !mat) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "no scene uploaded");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf dr, dhit, dtt, dp, dn, df, dm;
+    HIP_TRY(dr.put(ray6, sizeof(float) * 6 * n));
+    HIP_TRY(dhit.alloc(sizeof(int32_t) * n));
+    HIP_TRY(dtt.alloc(sizeof(float) * n));
+    HIP_TRY(dp.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(dn.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(df.alloc(sizeof(int32_t) * n));
+    HIP_TRY(dm.alloc(sizeof(int32_t) * n));
+    HIP_TRY(PICK(flags, launch_test_hit_list_)(ctx->scene, n, dr.as<float>(), dhit.as<int32_t>(), dtt.as<float>(),
+                                               dp.as<float>(), dn.as<float>(), df.as<int32_t>(), dm.as<int32_t>(),
+                                               ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dhit.get(hit, sizeof(int32_t) * n));
+    HIP_TRY(dtt.get(t, sizeof(float) * n));
+    HIP_TRY(dp.get(p3, sizeof(float) * 3 * n));
+    HIP_TRY(dn.get(n3, sizeof(float) * 3 * n));
+    HIP_TRY(df.get(face, sizeof(int32_t) * n));
+    HIP_TRY(dm.get(mat, sizeof(int32_t) * n));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_test_scatter(caster_hip_ctx* ctx, uint32_t flags, int n,
+                            const float* ray6, const float* p3, const float* n3,
+                            const int32_t* face, const int32_t* mat, uint32_t seed,
+                            int32_t* ok, float* out_ray6, int32_t* draws)
+{
+    if (!ctx || !ray6 || !p3 || !n3 || !face || !mat || !ok || !out_ray6 || !draws)
+        return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "no scene uploaded");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    for (int k = 0; k < n; ++k)
+        if (mat[k] < 0 || mat[k] >= ctx->scene.n_mat)
+            return fail(CASTER_HIP_ERR_ARG, "mat[%d] = %d out of range [0, %d)", k, mat[k], ctx->scene.n_mat);
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf dr, dp, dn, df, dm, dok, dout, dd;
+    HIP_TRY(dr.put(ray6, sizeof(float) * 6 * n));
+    HIP_TRY(dp.put(p3, sizeof(float) * 3 * n));
+    HIP_TRY(dn.put(n3, sizeof(float) * 3 * n));
+    HIP_TRY(df.put(face, sizeof(int32_t) * n));
+    HIP_TRY(dm.put(mat, sizeof(int32_t) * n));
+    HIP_TRY(dok.alloc(sizeof(int32_t) * n));
+    HIP_TRY(dout.alloc(sizeof(float) * 6 * n));
+    HIP_TRY(dd.alloc(sizeof(int32_t) * n));
+    HIP_TRY(PICK(flags, launch_test_scatter_)(ctx->scene, n, dr.as<float>(), dp.as<float>(), dn.as<float>(),
+                                              df.as<int32_t>(), dm.as<int32_t>(), seed, dok.as<int32_t>(),
+                                              dout.as<float>(), dd.as<int32_t>(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dok.get(ok, sizeof(int32_t) * n));
+    HIP_TRY(dout.get(out_ray6, sizeof(float) * 6 * n));
+    HIP_TRY(dd.get(draws, sizeof(int32_t) * n));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_test_camera_ray(caster_hip_ctx* ctx, uint32_t flags, const caster_camera* cam,
+                               int n, const float* uv2, uint32_t seed, float* out_ray6, int32_t* draws)
+{
+    if (!ctx || !cam || !uv2 || !out_ray6 || !draws) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf duv, dout, dd;
+    HIP_TRY(duv.put(uv2, sizeof(float) * 2 * n));
+    HIP_TRY(dout.alloc(sizeof(float) * 6 * n));
+    HIP_TRY(dd.alloc(sizeof(int32_t) * n));
+    HIP_TRY(PICK(flags, launch_test_camera_)(cam_rec(cam), n, duv.as<float>(), seed, dout.as<float>(),
+                                             dd.as<int32_t>(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dout.get(out_ray6, sizeof(float) * 6 * n));
+    HIP_TRY(dd.get(draws, sizeof(int32_t) * n));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_test_texture(caster_hip_ctx* ctx, uint32_t flags, int n, const int32_t* mat,
+                            const float* uv2, const float* p3, float* rgb3)
+{
+    if (!ctx || !mat || !uv2 || !p3 || !rgb3) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "no scene uploaded");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    for (int k = 0; k < n; ++k)
+        if (mat[k] < 0 || mat[k] >= ctx->scene.n_mat)
+            return fail(CASTER_HIP_ERR_ARG, "mat[%d] = %d out of range [0, %d)", k, mat[k], ctx->scene.n_mat);
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf dm, duv, dp, dout;
+    HIP_TRY(dm.put(mat, sizeof(int32_t) * n));
+    HIP_TRY(duv.put(uv2, sizeof(float) * 2 * n));
+    HIP_TRY(dp.put(p3, sizeof(float) * 3 * n));
+    HIP_TRY(dout.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(PICK(flags, launch_test_texture_)(ctx->scene, n, dm.as<int32_t>(), duv.as<float>(), dp.as<float>(),
+                                              dout.as<float>(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dout.get(rgb3, sizeof(float) * 3 * n));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_test_rng(caster_hip_ctx* ctx, uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24)
+{
+    if (!ctx || !out24) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf d;
+    HIP_TRY(d.alloc(sizeof(uint32_t) * n));
+    HIP_TRY(caster::launch_test_rng(seed, pixel, sample, n, d.as<uint32_t>(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(d.get(out24, sizeof(uint32_t) * n));
+    return CASTER_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,403 @@
+// Device-side math, random stream, intersection, scattering and texturing for
+// the gfx950 path tracer.  This header is compiled twice:
+//   * caster_strict.hip  (CASTER_STRICT=1, -ffp-contract=off): every expression
+//     keeps the reference's association order, so no FMA is formed, divide and
+//     sqrt are the correctly rounded forms, and libm calls are evaluated in
+//     double and rounded once;
+//   * caster_fast.hip    (CASTER_STRICT=0): the compiler may contract to FMA.
+// Each function cites the reference lines whose result it must reproduce.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef CASTER_STRICT
+#error "define CASTER_STRICT to 0 or 1 before including caster_device.hpp"
+#endif
+
+#define CDEV __device__ __forceinline__
+
+namespace caster {
+
+constexpr float kPi = 3.141592654f;      // inc/common.h:10
+constexpr float kTMin = 0.001f;          // src/caster.c:441
+constexpr float kTMax = 16777215.0f;     // src/caster.c:441 (0xFFFFFF)
+
+struct V3 { float x, y, z; };
+struct V2 { float u, v; };
+struct Ray { V3 o, d; };
+
+// Flat material / image records as the host uploads them.
+struct Mat {
+    int32_t type, tex;
+    float c0[3], c1[3];
+    float fuzz, ior;
+    int32_t image, pad;
+};
+struct Img {
+    const uint8_t* data;
+    uint32_t w, h, bpp, pad;
+};
+struct Cam { V3 o, llc, h, v, u0, v0; float lr; };
+
+// Scene as the kernels see it.  Spheres and rects keep their list positions
+// (ord) so that a tie in t can go to the later list entry, as the reference's
+// in-order loop does (src/caster.c:114,136,204).
+struct SceneView {
+    const float4* sph;      // cx, cy, cz, r
+    const int2*   sph_meta; // list position, material
+    const float4* rect_a;   // cx, cy, cz, du
+    const float4* rect_b;   // dv, -, -, -
+    const int2*   rect_meta;
+    const Mat*    mats;
+    const Img*    imgs;
+    int n_sph, n_rect, n_mat, n_img;
+};
+
+CDEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+CDEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }   // common.c:45-53
+CDEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }   // common.c:55-63
+CDEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }   // common.c:65-72
+CDEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }      // common.c:33
+CDEV V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }      // common.c:34
+CDEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }                              // common.c:36-43
+CDEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y + a.z * b.z); }      // common.c:84-87
+CDEV V3 to_unit(V3 v) { return v / sqrtf(dot(v, v)); }                          // common.c:89-97
+
+// ------------------------------------------------------------------ RNG --
+// Replaces rand() (src/common.c:10-13).  The stream for one path is keyed by
+// (seed, pixel, sample): SplitMix64 of the key gives the start state of a
+// PCG-XSH-RR 64/32 generator; a draw is its top 24 bits, random_f32 = n/2^24.
+struct Rng { uint64_t s; uint32_t draws; };
+
+CDEV uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+CDEV void rng_seed(Rng& g, uint32_t seed, uint32_t pixel, uint32_t sample)
+{
+    uint64_t z = ((uint64_t)pixel << 32) | (uint64_t)sample;
+    z ^= (uint64_t)seed * 0x9E3779B97F4A7C15ull;
+    g.s = mix64(z);
+    g.draws = 0;
+}
+
+CDEV uint32_t rng_next24(Rng& g)
+{
+    uint64_t old = g.s;
+    g.s = old * 6364136223846793005ull + 1442695040888963407ull;
+    uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+    uint32_t rot = (uint32_t)(old >> 59);
+    uint32_t out = (xs >> rot) | (xs << ((32u - rot) & 31u));
+    return out >> 8;
+}
+
+CDEV float random_f32(Rng& g)                                   // common.c:10-13
+{
+    g.draws++;
+    return (float)rng_next24(g) * 5.9604644775390625e-8f;       // n / 2^24, exact
+}
+
+CDEV float random_range_f32(Rng& g, float lo, float hi)         // common.c:15-18
+{
+    return lo + (hi - lo) * random_f32(g);
+}
+
+CDEV V3 random_unit_sphere(Rng& g)                              // common.c:108-126
+{
+    for (;;) {
+        V3 p;
+        p.x = random_range_f32(g, -1.0f, 1.0f);
+        p.y = random_range_f32(g, -1.0f, 1.0f);
+        p.z = random_range_f32(g, -1.0f, 1.0f);
+        if (dot(p, p) < 1.0f) return p;
+    }
+}
+
+CDEV V3 random_unit_disk(Rng& g)                                // common.c:128-136, x first
+{
+    for (;;) {
+        V3 p;
+        p.x = random_range_f32(g, -1.0f, 1.0f);
+        p.y = random_range_f32(g, -1.0f, 1.0f);
+        p.z = 0.0f;
+        if (dot(p, p) < 1.0f) return p;
+    }
+}
+
+CDEV V3 random_unit_norm(Rng& g) { return to_unit(random_unit_sphere(g)); }     // common.c:138-141
+
+CDEV bool near_zero(V3 v)                                       // common.c:152-156
+{
+    const float s = 1E-8f;
+    return (fabsf(v.x) < s) && (fabsf(v.y) < s) && (fabsf(v.z) < s);
+}
+
+CDEV V3 reflect(V3 v, V3 n) { return v - n * (2.0f * dot(v, n)); }              // common.c:158-161
+
+CDEV V3 refract(V3 unit_v, V3 n, float ratio, float cos_theta)  // common.c:163-168
+{
+    V3 orto = (unit_v + n * cos_theta) * ratio;
+    V3 para = n * -sqrtf(fabsf(1.0f - dot(orto, orto)));
+    return orto + para;
+}
+
+// libm calls.  The strict build evaluates them in double and rounds once,
+// which agrees with glibc's float results except where glibc itself is not
+// correctly rounded (last-ulp cases).
+CDEV float m_pow5(float x)
+{
+#if CASTER_STRICT
+    double d = (double)x;
+    return (float)(d * d * d * d * d);
+#else
+    float x2 = x * x;
+    return x2 * x2 * x;
+#endif
+}
+CDEV float m_sin(float x)
+{
+#if CASTER_STRICT
+    return (float)sin((double)x);
+#else
+    return sinf(x);
+#endif
+}
+CDEV float m_atan2(float y, float x)
+{
+#if CASTER_STRICT
+    return (float)atan2((double)y, (double)x);
+#else
+    return atan2f(y, x);
+#endif
+}
+CDEV float m_acos(float x)
+{
+#if CASTER_STRICT
+    return (float)acos((double)x);
+#else
+    return acosf(x);
+#endif
+}
+
+CDEV float reflectance(float cosine, float ratio)               // common.c:170-175
+{
+    float r0 = (1.0f - ratio) / (1.0f + ratio);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * m_pow5(1.0f - cosine);
+}
+
+// ---------------------------------------------------------- intersection --
+CDEV V3 ray_at(const Ray& r, float t) { return r.o + r.d * t; } // caster.c:5-8
+
+// One sphere against one ray inside the closest-hit loop (caster.c:99-121 up
+// to the accepted root).  s = {cx, cy, cz, r*r}.  Returns true and the root if
+// the sphere is accepted against the closest t so far.
+CDEV bool sphere_root(const float4 s, const V3& o, const V3& d, float a, float tmin, float tmax,
+                      float& root_out)
+{
+    V3 oc = mk(o.x - s.x, o.y - s.y, o.z - s.z);
+    float hb = dot(oc, d);
+    float c = dot(oc, oc) - s.w;
+    float disc = hb * hb - a * c;
+    if (disc < 0.0f) return false;
+    float sq = sqrtf(disc);
+    float root = (-hb - sq) / a;
+    if (root < tmin || root > tmax) {
+        root = (-hb + sq) / a;
+        if (root < tmin || root > tmax) return false;
+    }
+    root_out = root;
+    return true;
+}
+
+struct HitRec {
+    V3 p, n;
+    float t;
+    int f;
+    int m;
+    V2 uv;
+    bool uv_sphere;   // uv not yet computed: a sphere's uv is derived from the normal on demand
+    V3 outn;
+};
+
+CDEV void set_face(HitRec& rec, const Ray& r, V3 outn)          // caster.c:10-14
+{
+    rec.f = dot(r.d, outn) < 0.0f;
+    rec.n = rec.f ? outn : neg(outn);
+}
+
+// caster.c:123-128 for an accepted root.  The reference also evaluates
+// get_uv_coord here for every candidate; only image textures read uv, so it
+// is evaluated lazily from outn (same value).
+CDEV void finish_sphere(HitRec& rec, const Ray& r, float root, V3 center, float radius, int mat)
+{
+    rec.t = root;
+    rec.p = ray_at(r, root);
+    V3 outn = (rec.p - center) / radius;
+    set_face(rec, r, outn);
+    rec.outn = outn;
+    rec.uv_sphere = true;
+    rec.uv.u = 0.0f; rec.uv.v = 0.0f;
+    rec.m = mat;
+}
+
+CDEV V2 get_uv_coord_sphere(V3 p)                               // material.c:45-56
+{
+    V2 uv;
+    uv.u = (m_atan2(-p.z, p.x) + kPi) / (2.0f * kPi);
+    uv.v = m_acos(-p.y) / kPi;
+    return uv;
+}
+
+// caster.c:132-151: candidate t of an xy rect, independent of the closest hit.
+CDEV bool rect_root(const float4 ra, const float4 rb, const Ray& r, float tmin, float tmax, float& t_out)
+{
+    float t = (ra.z - r.o.z) / r.d.z;
+    if (t < tmin || t > tmax) return false;
+    float x = r.o.x + t * r.d.x;
+    float y = r.o.y + t * r.d.y;
+    float half_du = ra.w / 2.0f;
+    float half_dv = rb.x / 2.0f;
+    float x0 = ra.x - half_du, x1 = ra.x + half_du;
+    float y0 = ra.y - half_dv, y1 = ra.y + half_dv;
+    if (x < x0 || x > x1 || y < y0 || y > y1) return false;
+    t_out = t;
+    return true;
+}
+
+CDEV void finish_rect(HitRec& rec, const Ray& r, float t, const float4 ra, const float4 rb, int mat)
+{                                                               // caster.c:139-161
+    float x = r.o.x + t * r.d.x;
+    float y = r.o.y + t * r.d.y;
+    float x0 = ra.x - ra.w / 2.0f;
+    float y0 = ra.y - rb.x / 2.0f;
+    rec.uv.u = (x - x0) / ra.w;
+    rec.uv.v = (y - y0) / rb.x;
+    rec.uv_sphere = false;
+    rec.t = t;
+    set_face(rec, r, mk(0.0f, 0.0f, 1.0f));
+    rec.outn = mk(0.0f, 0.0f, 1.0f);
+    rec.m = mat;
+    rec.p = ray_at(r, t);
+}
+
+// -------------------------------------------------------------- materials --
+CDEV bool scatter_lambertian(Rng& g, const HitRec& rec, Ray& out)               // material.c:3-12
+{
+    out.o = rec.p;
+    out.d = rec.n + random_unit_norm(g);
+    if (near_zero(out.d)) out.d = rec.n;
+    return true;
+}
+
+CDEV bool scatter_metal(Rng& g, const Ray& r, const HitRec& rec, float fuzz, Ray& out)  // material.c:14-19
+{
+    out.o = rec.p;
+    V3 refl = reflect(to_unit(r.d), rec.n);
+    V3 fz = random_unit_sphere(g) * fuzz;
+    out.d = refl + fz;
+    return dot(out.d, rec.n) > 0.0f;
+}
+
+CDEV bool scatter_dielectric(Rng& g, const Ray& r, const HitRec& rec, float ior, Ray& out)  // material.c:21-43
+{
+    float rratio = rec.f ? (1.0f / ior) : ior;
+    out.o = rec.p;
+    V3 udir = to_unit(r.d);
+    V3 iudir = neg(udir);
+    float cos_theta = fminf(dot(iudir, rec.n), 1.0f);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    bool not_refract = rratio * sin_theta > 1.0f;
+    if (not_refract || reflectance(cos_theta, rratio) > random_f32(g))
+        out.d = reflect(udir, rec.n);
+    else
+        out.d = refract(udir, rec.n, rratio, cos_theta);
+    return true;
+}
+
+CDEV float clampf(float x, float lo, float hi)                  // common.c:25-29
+{
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+
+CDEV V3 texture_color(const SceneView& sc, const Mat& m, HitRec& rec)           // material.c:65-101
+{
+    switch (m.tex) {
+    case 0: // TTYPE_COLOR
+        return mk(m.c0[0], m.c0[1], m.c0[2]);
+    case 1: { // TTYPE_CHECKER
+        float sines = m_sin(10.0f * rec.p.x) * m_sin(10.0f * rec.p.y) * m_sin(10.0f * rec.p.z);
+        if (sines < 0.0f) return mk(m.c0[0], m.c0[1], m.c0[2]);
+        return mk(m.c1[0], m.c1[1], m.c1[2]);
+    }
+    case 2: { // TTYPE_IMAGE_ALBEDO
+        if (m.image < 0 || m.image >= sc.n_img) return mk(0.0f, 0.0f, 0.0f);
+        const Img im = sc.imgs[m.image];
+        V2 uv = rec.uv_sphere ? get_uv_coord_sphere(rec.outn) : rec.uv;
+        uv.u = clampf(uv.u, 0.0f, 1.0f);
+        uv.v = clampf(uv.v, 0.0f, 1.0f);
+        uint32_t i = (uint32_t)(uv.u * (float)im.w);
+        uint32_t j = (uint32_t)(uv.v * (float)im.h);
+        if (i >= im.w) i = im.w - 1;
+        if (j >= im.h) j = im.h - 1;
+        const float color_scale = 1.0f / 255.0f;
+        const uint8_t* pix = im.data + (size_t)j * im.w * im.bpp + (size_t)i * im.bpp;
+        return mk(color_scale * (float)pix[0], color_scale * (float)pix[1], color_scale * (float)pix[2]);
+    }
+    default:
+        return mk(0.0f, 0.0f, 0.0f);
+    }
+}
+
+// ----------------------------------------------------------------- camera --
+CDEV Ray ray_from_cam(const Cam& ci, Rng& g, float u, float v)  // camera.c:32-42
+{
+    Ray r;
+    V3 rd = random_unit_disk(g) * ci.lr;
+    V3 offset = ci.u0 * rd.x + ci.v0 * rd.y;
+    r.o = ci.o + offset;
+    r.d = ci.llc + (ci.h * u + ((ci.v * v - ci.o) - offset));
+    return r;
+}
+
+// --------------------------------------------------------------- shading --
+// What ray_color does after hit_list_hit_all returns a hit (caster.c:441-480),
+// unrolled from recursion: returns true when the path continues along `next`
+// with its throughput multiplied by `atten`; false when the path ends with
+// radiance `emit` (black for a failed scatter or an unknown tag).
+CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& next, V3& atten, V3& emit)
+{
+    const Mat m = sc.mats[rec.m];
+    emit = mk(0.0f, 0.0f, 0.0f);
+    atten = mk(1.0f, 1.0f, 1.0f);
+    switch (m.type) {
+    case 0: // MTYPE_LAMBERTIAN
+        scatter_lambertian(g, rec, next);
+        atten = texture_color(sc, m, rec);
+        return true;
+    case 1: // MTYPE_METAL
+        if (scatter_metal(g, r, rec, m.fuzz, next)) {
+            atten = texture_color(sc, m, rec);
+            return true;
+        }
+        return false;
+    case 2: // MTYPE_DIELECTRIC
+        scatter_dielectric(g, r, rec, m.ior, next);
+        return true;
+    case 3: // MTYPE_DIFF_LIGHT
+        if (m.tex == 0) emit = mk(m.c0[0], m.c0[1], m.c0[2]);
+        else if (m.tex == 2) emit = texture_color(sc, m, rec);
+        return false;
+    default:
+        return false;
+    }
+}
+
+}  // namespace caster

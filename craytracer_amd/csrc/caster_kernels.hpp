@@ -1,0 +1,419 @@
+// Kernels of the gfx950 path tracer, compiled once per arithmetic mode (see
+// caster_device.hpp).  The including .hip file defines CASTER_STRICT and
+// CASTER_SFX (strict / fast).
+#pragma once
+
+#include "caster_device.hpp"
+#include "caster_launch.h"
+
+#define CASTER_CAT2(a, b) a##b
+#define CASTER_CAT(a, b) CASTER_CAT2(a, b)
+#define CASTER_NAME(base) CASTER_CAT(base, CASTER_SFX)
+
+namespace caster {
+
+constexpr int kBlock = 256;       // 4 waves
+constexpr int kSphTile = 1024;    // spheres staged in LDS at a time (16 KiB)
+constexpr int kTileW = 8, kTileH = 8;
+
+static_assert(sizeof(MatRec) == sizeof(Mat), "material record layout");
+static_assert(sizeof(ImgRec) == sizeof(Img), "image record layout");
+static_assert(sizeof(CamRec) == sizeof(Cam), "camera record layout");
+
+CDEV SceneView view_of(const SceneDev& s)
+{
+    SceneView v;
+    v.sph = s.sph; v.sph_meta = s.sph_meta;
+    v.rect_a = s.rect_a; v.rect_b = s.rect_b; v.rect_meta = s.rect_meta;
+    v.mats = reinterpret_cast<const Mat*>(s.mats);
+    v.imgs = reinterpret_cast<const Img*>(s.imgs);
+    v.n_sph = s.n_sph; v.n_rect = s.n_rect; v.n_mat = s.n_mat; v.n_img = s.n_img;
+    return v;
+}
+
+CDEV Cam cam_of(const CamRec& c)
+{
+    Cam k;
+    k.o = mk(c.o[0], c.o[1], c.o[2]);
+    k.llc = mk(c.llc[0], c.llc[1], c.llc[2]);
+    k.h = mk(c.h[0], c.h[1], c.h[2]);
+    k.v = mk(c.v[0], c.v[1], c.v[2]);
+    k.u0 = mk(c.u0[0], c.u0[1], c.u0[2]);
+    k.v0 = mk(c.v0[0], c.v0[1], c.v0[2]);
+    k.lr = c.lr;
+    return k;
+}
+
+// Closest hit of the rect list, merged into the result of the sphere loop.
+// best_ord is the list position of the current winner; an equal t goes to the
+// later list entry, which is what the reference's in-order loop produces.
+CDEV void closest_rects(const SceneView& sc, const Ray& r, float& closest, int& best_ord,
+                        int& best_rect)
+{
+    for (int k = 0; k < sc.n_rect; ++k) {
+        float t;
+        if (rect_root(sc.rect_a[k], sc.rect_b[k], r, kTMin, closest, t)) {
+            int ord = sc.rect_meta[k].x;
+            if (t < closest || ord > best_ord || best_ord < 0) {
+                closest = t; best_ord = ord; best_rect = k;
+            }
+        }
+    }
+}
+
+// Camera ray for sample s of pixel (i, j): src/dispatcher.c:21-24.
+CDEV void start_path(const Cam& cam, int width, int height, int i, int j, int s, uint32_t seed,
+                     Rng& g, Ray& r)
+{
+    rng_seed(g, seed, (uint32_t)(j * width + i), (uint32_t)s);
+    float u = ((float)i + random_f32(g)) / (float)(width - 1);
+    float v = ((float)j + random_f32(g)) / (float)(height - 1);
+    r = ray_from_cam(cam, g, u, v);
+}
+
+// One wave owns an 8x8 pixel tile and one chunk of the sample range; a lane
+// owns one pixel and walks its samples in order, starting the next camera ray
+// as soon as a path ends.  Every loop trip tests the lane's current ray
+// against the whole sphere list, staged through LDS in tiles of kSphTile.
+__global__ __launch_bounds__(kBlock)
+void CASTER_NAME(render_kernel_)(RenderArgs a)
+{
+    __shared__ float4 s_sph[kSphTile];
+
+    const SceneView sc = view_of(a.scene);
+    const Cam cam = cam_of(a.cam);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tiles_x = (a.width + kTileW - 1) / kTileW;
+    const int tiles_y = (a.height + kTileH - 1) / kTileH;
+    const int n_tiles = tiles_x * tiles_y;
+    const int unit = blockIdx.x * (kBlock / 64) + wave;
+    const int chunk = unit / n_tiles;
+    const int tile = unit - chunk * n_tiles;
+    const int i = (tile % tiles_x) * kTileW + (lane & 7);
+    const int j = (tile / tiles_x) * kTileH + (lane >> 3);
+    const bool valid = (chunk < a.n_chunks) && (i < a.width) && (j < a.height);
+    const int s0 = a.s_begin + chunk * a.chunk;
+    const int s_end = a.s_begin + a.s_count;
+    const int s1 = (s0 + a.chunk < s_end) ? s0 + a.chunk : s_end;
+
+    const bool tiled = sc.n_sph > kSphTile;
+    if (!tiled) {
+        for (int k = threadIdx.x; k < sc.n_sph; k += kBlock) {
+            float4 s = sc.sph[k];
+            s.w = s.w * s.w;
+            s_sph[k] = s;
+        }
+        __syncthreads();
+    }
+
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    int s = s0;
+    bool alive = valid && (s < s1) && (a.max_depth > 0);
+    Ray r;
+    r.o = mk(0.0f, 0.0f, 0.0f);
+    r.d = mk(0.0f, 0.0f, 1.0f);
+    V3 thr = mk(1.0f, 1.0f, 1.0f);
+    int depth = a.max_depth;
+    Rng g;
+    g.s = 0; g.draws = 0;
+    unsigned int rays = 0;
+    if (alive) start_path(cam, a.width, a.height, i, j, s, a.seed, g, r);
+
+    for (;;) {
+        const bool any_alive = tiled ? (__syncthreads_or(alive ? 1 : 0) != 0) : (__any(alive ? 1 : 0) != 0);
+        if (!any_alive) break;
+
+        float closest = kTMax;
+        int best_sph = -1;
+        const float aa = dot(r.d, r.d);
+        if (!tiled) {
+            if (alive) {
+                for (int k = 0; k < sc.n_sph; ++k) {
+                    float root;
+                    if (sphere_root(s_sph[k], r.o, r.d, aa, kTMin, closest, root)) {
+                        closest = root; best_sph = k;
+                    }
+                }
+            }
+        } else {
+            for (int base = 0; base < sc.n_sph; base += kSphTile) {
+                const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
+                __syncthreads();
+                for (int k = threadIdx.x; k < cnt; k += kBlock) {
+                    float4 sp = sc.sph[base + k];
+                    sp.w = sp.w * sp.w;
+                    s_sph[k] = sp;
+                }
+                __syncthreads();
+                if (alive) {
+                    for (int k = 0; k < cnt; ++k) {
+                        float root;
+                        if (sphere_root(s_sph[k], r.o, r.d, aa, kTMin, closest, root)) {
+                            closest = root; best_sph = base + k;
+                        }
+                    }
+                }
+            }
+        }
+
+        if (alive) {
+            rays++;
+            int best_ord = (best_sph >= 0) ? sc.sph_meta[best_sph].x : -1;
+            int best_rect = -1;
+            closest_rects(sc, r, closest, best_ord, best_rect);
+
+            bool cont = false;
+            V3 radiance = mk(0.0f, 0.0f, 0.0f);
+            if (best_ord >= 0) {
+                HitRec rec;
+                if (best_rect >= 0) {
+                    finish_rect(rec, r, closest, sc.rect_a[best_rect], sc.rect_b[best_rect],
+                                sc.rect_meta[best_rect].y);
+                } else {
+                    const float4 sp = sc.sph[best_sph];
+                    finish_sphere(rec, r, closest, mk(sp.x, sp.y, sp.z), sp.w, sc.sph_meta[best_sph].y);
+                }
+                Ray next;
+                V3 atten, emit;
+                cont = shade(sc, g, r, rec, next, atten, emit);
+                if (cont) {
+                    thr = thr * atten;
+                    r = next;
+                    depth--;
+                    if (depth <= 0) cont = false;   // ray_color(depth 0) is black, uncounted
+                } else {
+                    radiance = thr * emit;
+                }
+            }
+            if (!cont) {
+                sum = sum + radiance;
+                s++;
+                if (s < s1) {
+                    start_path(cam, a.width, a.height, i, j, s, a.seed, g, r);
+                    thr = mk(1.0f, 1.0f, 1.0f);
+                    depth = a.max_depth;
+                } else {
+                    alive = false;
+                }
+            }
+        }
+    }
+
+    if (valid) {
+        const int done = (s1 > s0) ? (s1 - s0) : 0;
+        a.slabs[(size_t)chunk * a.width * a.height + (size_t)j * a.width + i] =
+            make_float4(sum.x, sum.y, sum.z, (float)done);
+    }
+
+    // one ray-count atomic per wave
+    unsigned int wrays = rays;
+    for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
+    if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
+}
+
+hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a, hipStream_t st)
+{
+    const int tiles_x = (a.width + kTileW - 1) / kTileW;
+    const int tiles_y = (a.height + kTileH - 1) / kTileH;
+    const long long units = (long long)tiles_x * tiles_y * a.n_chunks;
+    const long long blocks = (units + (kBlock / 64) - 1) / (kBlock / 64);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(CASTER_NAME(render_kernel_), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------ test kernels --
+__global__ void CASTER_NAME(k_test_hit_sphere_)(int n, const float* sph4, const float* ray6, const float* tr2,
+                                                int32_t* hit, float* t, float* p3, float* n3, int32_t* face)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Ray r;
+    r.o = mk(ray6[6 * k], ray6[6 * k + 1], ray6[6 * k + 2]);
+    r.d = mk(ray6[6 * k + 3], ray6[6 * k + 4], ray6[6 * k + 5]);
+    float radius = sph4[4 * k + 3];
+    float4 s = make_float4(sph4[4 * k], sph4[4 * k + 1], sph4[4 * k + 2], radius * radius);
+    float root;
+    bool ok = sphere_root(s, r.o, r.d, dot(r.d, r.d), tr2[2 * k], tr2[2 * k + 1], root);
+    HitRec rec;
+    rec.t = 0; rec.f = 0; rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0);
+    if (ok) finish_sphere(rec, r, root, mk(s.x, s.y, s.z), radius, 0);
+    hit[k] = ok; t[k] = rec.t; face[k] = rec.f;
+    p3[3 * k] = rec.p.x; p3[3 * k + 1] = rec.p.y; p3[3 * k + 2] = rec.p.z;
+    n3[3 * k] = rec.n.x; n3[3 * k + 1] = rec.n.y; n3[3 * k + 2] = rec.n.z;
+}
+
+__global__ void CASTER_NAME(k_test_hit_rect_)(int n, const float* rect5, const float* ray6, const float* tr2,
+                                              int32_t* hit, float* t, float* p3, float* n3, int32_t* face,
+                                              float* uv2)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Ray r;
+    r.o = mk(ray6[6 * k], ray6[6 * k + 1], ray6[6 * k + 2]);
+    r.d = mk(ray6[6 * k + 3], ray6[6 * k + 4], ray6[6 * k + 5]);
+    float4 ra = make_float4(rect5[5 * k], rect5[5 * k + 1], rect5[5 * k + 2], rect5[5 * k + 3]);
+    float4 rb = make_float4(rect5[5 * k + 4], 0, 0, 0);
+    float tt;
+    bool ok = rect_root(ra, rb, r, tr2[2 * k], tr2[2 * k + 1], tt);
+    HitRec rec;
+    rec.t = 0; rec.f = 0; rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.uv.u = 0; rec.uv.v = 0;
+    if (ok) finish_rect(rec, r, tt, ra, rb, 0);
+    hit[k] = ok; t[k] = rec.t; face[k] = rec.f;
+    p3[3 * k] = rec.p.x; p3[3 * k + 1] = rec.p.y; p3[3 * k + 2] = rec.p.z;
+    n3[3 * k] = rec.n.x; n3[3 * k + 1] = rec.n.y; n3[3 * k + 2] = rec.n.z;
+    uv2[2 * k] = rec.uv.u; uv2[2 * k + 1] = rec.uv.v;
+}
+
+// hit_list_hit_all straight from global memory (no LDS staging): the same
+// device functions as the render kernel, one ray per thread.
+CDEV bool closest_hit_global(const SceneView& sc, const Ray& r, HitRec& rec)
+{
+    float closest = kTMax;
+    int best_sph = -1;
+    const float aa = dot(r.d, r.d);
+    for (int k = 0; k < sc.n_sph; ++k) {
+        float4 s = sc.sph[k];
+        s.w = s.w * s.w;
+        float root;
+        if (sphere_root(s, r.o, r.d, aa, kTMin, closest, root)) { closest = root; best_sph = k; }
+    }
+    int best_ord = (best_sph >= 0) ? sc.sph_meta[best_sph].x : -1;
+    int best_rect = -1;
+    closest_rects(sc, r, closest, best_ord, best_rect);
+    if (best_ord < 0) return false;
+    if (best_rect >= 0) {
+        finish_rect(rec, r, closest, sc.rect_a[best_rect], sc.rect_b[best_rect], sc.rect_meta[best_rect].y);
+    } else {
+        const float4 sp = sc.sph[best_sph];
+        finish_sphere(rec, r, closest, mk(sp.x, sp.y, sp.z), sp.w, sc.sph_meta[best_sph].y);
+    }
+    return true;
+}
+
+__global__ void CASTER_NAME(k_test_hit_list_)(SceneDev sd, int n, const float* ray6, int32_t* hit, float* t,
+                                              float* p3, float* n3, int32_t* face, int32_t* mat)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const SceneView sc = view_of(sd);
+    Ray r;
+    r.o = mk(ray6[6 * k], ray6[6 * k + 1], ray6[6 * k + 2]);
+    r.d = mk(ray6[6 * k + 3], ray6[6 * k + 4], ray6[6 * k + 5]);
+    HitRec rec;
+    rec.t = 0; rec.f = 0; rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.m = -1;
+    bool ok = closest_hit_global(sc, r, rec);
+    hit[k] = ok; t[k] = rec.t; face[k] = rec.f; mat[k] = ok ? rec.m : -1;
+    p3[3 * k] = rec.p.x; p3[3 * k + 1] = rec.p.y; p3[3 * k + 2] = rec.p.z;
+    n3[3 * k] = rec.n.x; n3[3 * k + 1] = rec.n.y; n3[3 * k + 2] = rec.n.z;
+}
+
+__global__ void CASTER_NAME(k_test_scatter_)(SceneDev sd, int n, const float* ray6, const float* p3,
+                                             const float* n3, const int32_t* face, const int32_t* mat,
+                                             uint32_t seed, int32_t* ok, float* out6, int32_t* draws)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const SceneView sc = view_of(sd);
+    Ray r;
+    r.o = mk(ray6[6 * k], ray6[6 * k + 1], ray6[6 * k + 2]);
+    r.d = mk(ray6[6 * k + 3], ray6[6 * k + 4], ray6[6 * k + 5]);
+    HitRec rec;
+    rec.p = mk(p3[3 * k], p3[3 * k + 1], p3[3 * k + 2]);
+    rec.n = mk(n3[3 * k], n3[3 * k + 1], n3[3 * k + 2]);
+    rec.f = face[k];
+    rec.m = mat[k];
+    Rng g;
+    rng_seed(g, seed, (uint32_t)k, 0u);
+    Ray out;
+    out.o = mk(0, 0, 0); out.d = mk(0, 0, 0);
+    bool res = false;
+    const Mat m = sc.mats[rec.m];
+    if (m.type == 0) res = scatter_lambertian(g, rec, out);
+    else if (m.type == 1) res = scatter_metal(g, r, rec, m.fuzz, out);
+    else if (m.type == 2) res = scatter_dielectric(g, r, rec, m.ior, out);
+    ok[k] = res;
+    out6[6 * k] = out.o.x; out6[6 * k + 1] = out.o.y; out6[6 * k + 2] = out.o.z;
+    out6[6 * k + 3] = out.d.x; out6[6 * k + 4] = out.d.y; out6[6 * k + 5] = out.d.z;
+    draws[k] = (int32_t)g.draws;
+}
+
+__global__ void CASTER_NAME(k_test_camera_)(CamRec cr, int n, const float* uv2, uint32_t seed, float* out6,
+                                            int32_t* draws)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const Cam cam = cam_of(cr);
+    Rng g;
+    rng_seed(g, seed, (uint32_t)k, 0u);
+    Ray r = ray_from_cam(cam, g, uv2[2 * k], uv2[2 * k + 1]);
+    out6[6 * k] = r.o.x; out6[6 * k + 1] = r.o.y; out6[6 * k + 2] = r.o.z;
+    out6[6 * k + 3] = r.d.x; out6[6 * k + 4] = r.d.y; out6[6 * k + 5] = r.d.z;
+    draws[k] = (int32_t)g.draws;
+}
+
+__global__ void CASTER_NAME(k_test_texture_)(SceneDev sd, int n, const int32_t* mat, const float* uv2,
+                                             const float* p3, float* rgb3)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const SceneView sc = view_of(sd);
+    HitRec rec;
+    rec.p = mk(p3[3 * k], p3[3 * k + 1], p3[3 * k + 2]);
+    rec.uv.u = uv2[2 * k]; rec.uv.v = uv2[2 * k + 1];
+    rec.uv_sphere = false;
+    V3 c = texture_color(sc, sc.mats[mat[k]], rec);
+    rgb3[3 * k] = c.x; rgb3[3 * k + 1] = c.y; rgb3[3 * k + 2] = c.z;
+}
+
+static inline dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
+
+hipError_t CASTER_NAME(launch_test_hit_sphere_)(int n, const float* sph4, const float* ray6, const float* tr2,
+                                                int32_t* hit, float* t, float* p3, float* n3, int32_t* face,
+                                                hipStream_t st)
+{
+    hipLaunchKernelGGL(CASTER_NAME(k_test_hit_sphere_), grid_for(n), dim3(256), 0, st, n, sph4, ray6, tr2, hit,
+                       t, p3, n3, face);
+    return hipGetLastError();
+}
+hipError_t CASTER_NAME(launch_test_hit_rect_)(int n, const float* rect5, const float* ray6, const float* tr2,
+                                              int32_t* hit, float* t, float* p3, float* n3, int32_t* face,
+                                              float* uv2, hipStream_t st)
+{
+    hipLaunchKernelGGL(CASTER_NAME(k_test_hit_rect_), grid_for(n), dim3(256), 0, st, n, rect5, ray6, tr2, hit,
+                       t, p3, n3, face, uv2);
+    return hipGetLastError();
+}
+hipError_t CASTER_NAME(launch_test_hit_list_)(const SceneDev& sc, int n, const float* ray6, int32_t* hit,
+                                              float* t, float* p3, float* n3, int32_t* face, int32_t* mat,
+                                              hipStream_t st)
+{
+    hipLaunchKernelGGL(CASTER_NAME(k_test_hit_list_), grid_for(n), dim3(256), 0, st, sc, n, ray6, hit, t, p3,
+                       n3, face, mat);
+    return hipGetLastError();
+}
+hipError_t CASTER_NAME(launch_test_scatter_)(const SceneDev& sc, int n, const float* ray6, const float* p3,
+                                             const float* n3, const int32_t* face, const int32_t* mat,
+                                             uint32_t seed, int32_t* ok, float* out6, int32_t* draws,
+                                             hipStream_t st)
+{
+    hipLaunchKernelGGL(CASTER_NAME(k_test_scatter_), grid_for(n), dim3(256), 0, st, sc, n, ray6, p3, n3, face,
+                       mat, seed, ok, out6, draws);
+    return hipGetLastError();
+}
+hipError_t CASTER_NAME(launch_test_camera_)(const CamRec& cam, int n, const float* uv2, uint32_t seed,
+                                            float* out6, int32_t* draws, hipStream_t st)
+{
+    hipLaunchKernelGGL(CASTER_NAME(k_test_camera_), grid_for(n), dim3(256), 0, st, cam, n, uv2, seed, out6,
+                       draws);
+    return hipGetLastError();
+}
+hipError_t CASTER_NAME(launch_test_texture_)(const SceneDev& sc, int n, const int32_t* mat, const float* uv2,
+                                             const float* p3, float* rgb3, hipStream_t st)
+{
+    hipLaunchKernelGGL(CASTER_NAME(k_test_texture_), grid_for(n), dim3(256), 0, st, sc, n, mat, uv2, p3, rgb3);
+    return hipGetLastError();
+}
+
+}  // namespace caster

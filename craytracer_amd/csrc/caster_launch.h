@@ -1,0 +1,75 @@
+// Host-side launch interface between the C ABI (caster_api.cpp) and the two
+// device translation units (caster_strict.hip, caster_fast.hip).  Both units
+// export the same set of functions under a _strict / _fast suffix.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace caster {
+
+struct MatRec {            // == caster_material
+    int32_t type, tex;
+    float c0[3], c1[3];
+    float fuzz, ior;
+    int32_t image, pad;
+};
+struct ImgRec {
+    const uint8_t* data;   // device pointer
+    uint32_t w, h, bpp, pad;
+};
+struct CamRec { float o[3], llc[3], h[3], v[3], u0[3], v0[3]; float lr; };
+
+struct SceneDev {
+    const float4* sph;       // cx, cy, cz, r            (list order among spheres)
+    const int2*   sph_meta;  // list position, material
+    const float4* rect_a;    // cx, cy, cz, du
+    const float4* rect_b;    // dv, 0, 0, 0
+    const int2*   rect_meta;
+    const MatRec* mats;
+    const ImgRec* imgs;
+    int n_sph, n_rect, n_mat, n_img;
+};
+
+struct RenderArgs {
+    CamRec cam;
+    SceneDev scene;
+    int width, height;
+    int s_begin, s_count;    // sample range of this call
+    int chunk, n_chunks;     // samples per work unit, units per pixel tile
+    int max_depth;
+    uint32_t seed;
+    float4* slabs;           // n_chunks * width * height partial sums
+    unsigned long long* rays;
+};
+
+#define CASTER_DECLARE_LAUNCHERS(SFX)                                                             \
+    hipError_t launch_render_##SFX(const RenderArgs& a, hipStream_t st);                          \
+    hipError_t launch_test_hit_sphere_##SFX(int n, const float* sph4, const float* ray6,          \
+                                            const float* tr2, int32_t* hit, float* t, float* p3,  \
+                                            float* n3, int32_t* face, hipStream_t st);            \
+    hipError_t launch_test_hit_rect_##SFX(int n, const float* rect5, const float* ray6,           \
+                                          const float* tr2, int32_t* hit, float* t, float* p3,    \
+                                          float* n3, int32_t* face, float* uv2, hipStream_t st);  \
+    hipError_t launch_test_hit_list_##SFX(const SceneDev& sc, int n, const float* ray6,           \
+                                          int32_t* hit, float* t, float* p3, float* n3,           \
+                                          int32_t* face, int32_t* mat, hipStream_t st);           \
+    hipError_t launch_test_scatter_##SFX(const SceneDev& sc, int n, const float* ray6,            \
+                                         const float* p3, const float* n3, const int32_t* face,   \
+                                         const int32_t* mat, uint32_t seed, int32_t* ok,          \
+                                         float* out6, int32_t* draws, hipStream_t st);            \
+    hipError_t launch_test_camera_##SFX(const CamRec& cam, int n, const float* uv2, uint32_t seed,\
+                                        float* out6, int32_t* draws, hipStream_t st);             \
+    hipError_t launch_test_texture_##SFX(const SceneDev& sc, int n, const int32_t* mat,           \
+                                         const float* uv2, const float* p3, float* rgb3,          \
+                                         hipStream_t st);
+
+CASTER_DECLARE_LAUNCHERS(strict)
+CASTER_DECLARE_LAUNCHERS(fast)
+
+// Mode-independent kernels (defined in the strict unit).
+hipError_t launch_combine(const float4* slabs, int n_chunks, int n_pixels, float4* accum, hipStream_t st);
+hipError_t launch_resolve(const float4* accum, int width, int height, int spp, uint8_t* rgba, hipStream_t st);
+hipError_t launch_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24, hipStream_t st);
+
+}  // namespace caster

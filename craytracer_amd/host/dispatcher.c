@@ -1,0 +1,242 @@
+/* GPU re-host of the dispatcher job API (reference: src/dispatcher.c,
+ * inc/dispatcher.h).  The reference splits the frame into row blocks, one
+ * Win32 pool thread each, and every thread runs the per-pixel sample loop.
+ * Here a job is a GPU: job g renders samples [g*spp/G, (g+1)*spp/G) of every
+ * pixel through libcaster_hip, in batches so that progress counters can be
+ * published and a cancel request (atomic_window_running = 0) is honoured
+ * between batches; the fence sums the per-GPU radiance sums in GPU order and
+ * resolves them into the image buffer. */
+#include "craytracer.h"
+#include "caster_hip.h"
+
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/time.h>
+
+typedef struct {
+    ray_dispatcher* rd;
+    int id, device;
+    int s_begin, s_count;
+    caster_hip_ctx* ctx;
+    float* accum_dev;
+    float* accum_host;
+    int samples_done;
+    int status;
+    char err[256];
+} gpu_job;
+
+typedef struct {
+    int n_jobs;
+    int started;
+    pthread_t threads[MAX_THREADS];
+    gpu_job jobs[MAX_THREADS];
+    crt_flat_scene* flat;
+    u32 seed;
+    int strict;
+    i32 batch;
+} gpu_backend;
+
+static u64 now_us(void)
+{
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return (u64)tv.tv_sec * 1000000ull + (u64)tv.tv_usec;
+}
+
+static void job_fail(gpu_job* job, int status)
+{
+    job->status = status;
+    strncpy(job->err, caster_hip_last_error(), sizeof job->err - 1);
+    job->err[sizeof job->err - 1] = 0;
+    fprintf(stderr, "GPU job #%d (device %d): %s\n", job->id, job->device, job->err);
+}
+
+static void* job_main(void* arg)
+{
+    gpu_job* job = (gpu_job*)arg;
+    ray_dispatcher* rd = job->rd;
+    gpu_backend* be = (gpu_backend*)rd->backend;
+    const int id = job->id;
+    const size_t n_px = (size_t)rd->block_width * rd->block_height;
+    const size_t accum_bytes = n_px * 4 * sizeof(float);
+    int rc;
+
+    int n_obj = 0, n_mat = 0, n_img = 0;
+    crt_flat_counts(be->flat, &n_obj, &n_mat, &n_img);
+    if ((rc = caster_hip_create(job->device, &job->ctx)) ||
+        (rc = caster_hip_upload_scene(job->ctx, n_obj, (const caster_object*)crt_flat_objects(be->flat), n_mat,
+                                      (const caster_material*)crt_flat_materials(be->flat), n_img,
+                                      (const caster_image*)crt_flat_images(be->flat))) ||
+        (rc = caster_hip_malloc(job->ctx, accum_bytes, (void**)&job->accum_dev)) ||
+        (rc = caster_hip_memset_zero(job->ctx, job->accum_dev, accum_bytes))) {
+        job_fail(job, rc);
+        goto done;
+    }
+
+    {
+        caster_camera cam;
+        memcpy(&cam, rd->cam, sizeof cam);   /* cam_info and caster_camera share one layout */
+        const i32 batch = be->batch > 0 ? be->batch : job->s_count;
+        for (int s = job->s_begin; s < job->s_begin + job->s_count; s += batch) {
+            /* src/dispatcher.c:42-45: stop when the window was closed */
+            if (!__atomic_load_n(&rd->atomic_window_running, __ATOMIC_RELAXED)) break;
+            const int cnt = (s + batch <= job->s_begin + job->s_count) ? batch : job->s_begin + job->s_count - s;
+            const u64 t0 = now_us();
+            uint64_t rays = 0;
+            if ((rc = caster_hip_render(job->ctx, &cam, rd->block_width, rd->block_height, s, cnt, rd->max_depth,
+                                        be->seed, be->strict ? CASTER_HIP_STRICT : 0u, job->accum_dev)) ||
+                (rc = caster_hip_render_stats(job->ctx, &rays, NULL))) {
+                job_fail(job, rc);
+                goto done;
+            }
+            const u64 us = now_us() - t0;
+            job->samples_done += cnt;
+            /* src/dispatcher.c:36-40, per batch instead of per pixel */
+            __atomic_store_n(&rd->atomic_spp_counter[id], us ? us : 1, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&rd->atomic_spp_counter_total[id], us, __ATOMIC_RELAXED);
+            __atomic_store_n(&rd->atomic_spp_rays[id], (i32)rays, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&rd->atomic_spp_rays_total[id], (i32)rays, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&rd->rays_total[id], (u64)rays, __ATOMIC_RELAXED);
+        }
+    }
+
+    job->accum_host = (float*)malloc(accum_bytes);
+    if (!job->accum_host) { job->status = CASTER_HIP_ERR_ARG; goto done; }
+    if ((rc = caster_hip_download(job->ctx, job->accum_host, job->accum_dev, accum_bytes))) job_fail(job, rc);
+
+done:
+    printf("Thread #%d: Job finished!\n", id);                       /* src/dispatcher.c:50 */
+    __atomic_store_n(&rd->atomic_spp_counter[id], 1, __ATOMIC_RELAXED);  /* src/dispatcher.c:51-52 */
+    __atomic_store_n(&rd->atomic_spp_rays[id], 0, __ATOMIC_RELAXED);
+    return NULL;
+}
+
+ray_dispatcher new_ray_dispatcher(u8 num_threads, u8 blocks, i32 width, i32 height, i32 spp, i32 max_depth,
+                                  cam_info* cam, img_buffer* img, hit_list* list)
+{
+    (void)blocks;   /* the row-block count has no meaning for sample partitions */
+    ray_dispatcher d;
+    memset(&d, 0, sizeof d);
+    if (num_threads > MAX_THREADS) num_threads = MAX_THREADS;      /* src/dispatcher.c:63 */
+    int n_dev = 0;
+    if (caster_hip_device_count(&n_dev) != CASTER_HIP_OK || n_dev <= 0) {
+        fprintf(stderr, "new_ray_dispatcher: %s\n", caster_hip_last_error());
+        d.status = CASTER_HIP_ERR_DEVICE;
+        n_dev = 0;
+    }
+    int n_jobs = num_threads < 1 ? 1 : num_threads;
+    if (n_jobs > n_dev) n_jobs = n_dev;
+    if (spp > 0 && n_jobs > spp) n_jobs = spp;
+
+    gpu_backend* be = (gpu_backend*)calloc(1, sizeof(gpu_backend));
+    d.backend = be;
+    d.thread_count = (u8)n_jobs;
+    d.dispatch_mode = DMODE_PARALLELW;
+    d.last_id = 0;
+    d.max_depth = max_depth;
+    d.list = list;
+    d.atomic_window_running = 1;
+    d.block_size = n_jobs > 0 ? (spp + n_jobs - 1) / n_jobs : 0;
+    d.block_width = width;
+    d.block_height = height;
+    d.spp = spp;
+    d.cam = cam;
+    d.image = img;
+    if (be) {
+        be->n_jobs = n_jobs;
+        be->seed = 0xC0FFEEu;
+        be->strict = 0;
+        be->batch = 0;
+        be->flat = crt_flatten(list);
+        if (!be->flat) {
+            fprintf(stderr, "new_ray_dispatcher: the hit_list holds an object type the renderer does not define\n");
+            d.status = CASTER_HIP_ERR_ARG;
+        }
+    } else {
+        d.status = CASTER_HIP_ERR_ARG;
+    }
+    return d;
+}
+
+void ray_dispatcher_set_seed(ray_dispatcher* rd, u32 seed) { if (rd->backend) ((gpu_backend*)rd->backend)->seed = seed; }
+void ray_dispatcher_set_strict(ray_dispatcher* rd, int strict) { if (rd->backend) ((gpu_backend*)rd->backend)->strict = strict; }
+void ray_dispatcher_set_batch(ray_dispatcher* rd, i32 n) { if (rd->backend) ((gpu_backend*)rd->backend)->batch = n; }
+
+void ray_dispatcher_run_jobs(ray_dispatcher* rd)
+{
+    gpu_backend* be = (gpu_backend*)rd->backend;
+    if (!be || rd->status || be->started) return;
+    be->started = 1;
+    const int G = be->n_jobs;
+    for (int g = 0; g < G; g++) {
+        gpu_job* job = &be->jobs[g];
+        memset(job, 0, sizeof *job);
+        job->rd = rd;
+        job->id = g;
+        job->device = g;
+        job->s_begin = (int)(((long long)rd->spp * g) / G);
+        job->s_count = (int)(((long long)rd->spp * (g + 1)) / G) - job->s_begin;
+        if (pthread_create(&be->threads[g], NULL, job_main, job) != 0) {
+            job->status = CASTER_HIP_ERR_STATE;
+            rd->status = CASTER_HIP_ERR_STATE;
+        }
+        if (rd->last_id <= rd->thread_count) rd->last_id++;           /* src/dispatcher.c:111 */
+    }
+}
+
+clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
+{
+    gpu_backend* be = (gpu_backend*)rd->backend;
+    if (!be || !be->started) return clock();
+    const size_t n_px = (size_t)rd->block_width * rd->block_height;
+    for (int g = 0; g < be->n_jobs; g++) {
+        if (be->jobs[g].rd) pthread_join(be->threads[g], NULL);
+        if (be->jobs[g].status && !rd->status) rd->status = be->jobs[g].status;
+    }
+    if (!rd->status && be->n_jobs > 0) {
+        gpu_job* root = &be->jobs[0];
+        int done = root->samples_done;
+        /* radiance sums are linear: add them before the scale and the gamma (src/dispatcher.c:29-30) */
+        for (int g = 1; g < be->n_jobs; g++) {
+            const float* src = be->jobs[g].accum_host;
+            float* dst = root->accum_host;
+            for (size_t k = 0; k < n_px * 4; k++) dst[k] += src[k];
+            done += be->jobs[g].samples_done;
+        }
+        int rc = 0;
+        if (be->n_jobs > 1) {
+            /* upload the combined sums to job 0's GPU for the resolve */
+            float* tmp = NULL;
+            rc = caster_hip_free(root->ctx, root->accum_dev);
+            root->accum_dev = NULL;
+            if (!rc) rc = caster_hip_malloc(root->ctx, n_px * 16, (void**)&tmp);
+            root->accum_dev = tmp;
+            if (!rc) rc = caster_hip_upload(root->ctx, root->accum_dev, root->accum_host, n_px * 16);
+        }
+        if (!rc && done > 0 && rd->image && rd->image->data)
+            rc = caster_hip_resolve(root->ctx, root->accum_dev, rd->block_width, rd->block_height, done, rd->image->data);
+        if (rc) { job_fail(root, rc); rd->status = rc; }
+    }
+    for (int g = 0; g < be->n_jobs; g++) {
+        gpu_job* job = &be->jobs[g];
+        if (job->ctx) {
+            if (job->accum_dev) caster_hip_free(job->ctx, job->accum_dev);
+            caster_hip_destroy(job->ctx);
+        }
+        free(job->accum_host);
+        memset(job, 0, sizeof *job);
+    }
+    be->started = 0;
+    return clock();
+}
+
+void free_ray_dispatcher(ray_dispatcher* rd)
+{
+    gpu_backend* be = (gpu_backend*)rd->backend;
+    if (!be) return;
+    if (be->started) ray_dispatcher_worker_fence(rd);
+    crt_flat_free(be->flat);
+    free(be);
+    rd->backend = NULL;
+}

@@ -1,0 +1,224 @@
+"""Per-function parity of the HIP device functions (strict arithmetic mode) with the CPU
+restatement of the reference functions, called through the C ABI's array entry points.
+
+Bar (BASELINE north_star): t, normal and scatter direction within 2 ULP-scaled FP32 on
+identical inputs.  Everything that involves only +,-,*,/ and sqrt is in fact expected to be
+bit-identical; libm-backed results (Schlick powf, uv atan2/acos) may differ in the last place.
+"""
+import numpy as np
+import pytest
+
+from conftest import random_rays, scaled_ulp, ulp_distance
+
+pytestmark = pytest.mark.gpu
+
+ULP_TOL = 2.0
+
+
+def test_rng_stream_bit_exact(gpu, orc):
+    for seed, pixel, sample in [(0, 0, 0), (0xC0FFEE, 12345, 7), (0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF), (1, 1920 * 1080 - 1, 499)]:
+        a = gpu.test_rng(seed, pixel, sample, 257)
+        b = orc.rng(seed, pixel, sample, 257)
+        assert np.array_equal(a, b)
+        assert a.max() < (1 << 24)
+
+
+def _sphere_cases(rng, n):
+    """Spheres and rays that exercise: misses, two-root hits, origin inside, grazing, ground r=1000, sky r=1e5."""
+    sph = np.zeros((n, 4), np.float32)
+    rays = random_rays(rng, n)
+    kind = rng.integers(0, 6, size=n)
+    sph[:, :3] = rng.uniform(-12, 12, size=(n, 3))
+    sph[:, 3] = rng.uniform(0.1, 1.5, size=n)
+    # aim most rays at their sphere (with an offset up to ~1.3 r => hits, grazes and near misses)
+    aim = kind != 0
+    tgt = sph[:, :3] + rng.normal(size=(n, 3)).astype(np.float32) * (sph[:, 3:4] * rng.uniform(0, 1.3, size=(n, 1)).astype(np.float32))
+    d = (tgt - rays[:, :3]).astype(np.float32) * rng.uniform(0.1, 3.0, size=(n, 1)).astype(np.float32)
+    rays[aim, 3:] = d[aim]
+    inside = kind == 2
+    rays[inside, :3] = sph[inside, :3] + (rng.uniform(-0.5, 0.5, size=(inside.sum(), 3)) * sph[inside, 3:4]).astype(np.float32)
+    ground = kind == 3
+    sph[ground] = np.array([0, -1000, 0, 1000], np.float32)
+    sky = kind == 4
+    sph[sky] = np.array([0, 0, 0, 100000], np.float32)
+    tr = np.zeros((n, 2), np.float32)
+    tr[:, 0] = 0.001
+    tr[:, 1] = 16777215.0
+    shrink = rng.random(n) < 0.3   # closest-so-far smaller than the far root, sometimes than both
+    tr[shrink, 1] = rng.uniform(0.01, 3.0, size=shrink.sum())
+    return sph, rays, tr
+
+
+def test_hit_sphere_parity(gpu, orc):
+    rng = np.random.default_rng(101)
+    sph, rays, tr = _sphere_cases(rng, 6000)
+    g = gpu.test_hit_sphere(sph, rays, tr, strict=True)
+    o = orc.hit_sphere(sph, rays, tr)
+    assert np.array_equal(g["hit"], o["hit"])
+    assert 0.2 < o["hit"].mean() < 0.95
+    h = o["hit"] == 1
+    assert np.array_equal(g["face"][h], o["face"][h])
+    assert ulp_distance(g["t"][h], o["t"][h]).max() <= ULP_TOL
+    assert scaled_ulp(g["p"][h], o["p"][h], np.abs(o["p"][h]).max(axis=1, keepdims=True)).max() <= ULP_TOL
+    assert scaled_ulp(g["n"][h], o["n"][h], 1.0).max() <= ULP_TOL
+    # +,-,*,/ and sqrt only: expected identical bits
+    assert np.array_equal(g["t"][h], o["t"][h])
+    assert np.array_equal(g["n"][h], o["n"][h])
+
+
+def test_hit_xy_rect_parity(gpu, orc):
+    rng = np.random.default_rng(102)
+    n = 3000
+    rect = np.zeros((n, 5), np.float32)
+    rect[:, :3] = rng.uniform(-6, 6, size=(n, 3))
+    rect[:, 3:] = rng.uniform(0.5, 4, size=(n, 2))
+    rays = random_rays(rng, n)
+    tgt = rect[:, :3].copy()
+    tgt[:, :2] += (rng.uniform(-0.7, 0.7, size=(n, 2)) * rect[:, 3:]).astype(np.float32)
+    rays[:, 3:] = (tgt - rays[:, :3]) * rng.uniform(0.2, 2.0, size=(n, 1)).astype(np.float32)
+    tr = np.tile(np.array([0.001, 16777215.0], np.float32), (n, 1))
+    tr[rng.random(n) < 0.2, 1] = 0.5
+    # edge cases: ray parallel to the plane (dz = 0 -> inf), ray starting on the plane
+    rays[:5, 5] = 0.0
+    rays[5:10, 2] = rect[5:10, 2]
+    g = gpu.test_hit_xy_rect(rect, rays, tr, strict=True)
+    o = orc.hit_xy_rect(rect, rays, tr)
+    assert np.array_equal(g["hit"], o["hit"])
+    assert 0.1 < o["hit"].mean() < 0.9
+    h = o["hit"] == 1
+    for key in ("t", "p", "n", "uv"):
+        assert np.array_equal(g[key][h], o[key][h]), key
+    assert np.array_equal(g["face"][h], o["face"][h])
+
+
+@pytest.mark.parametrize("scene_name", ["scene_0", "rtiow", "ties"])
+def test_hit_list_parity(gpu, orc, ca, scene_name):
+    rng = np.random.default_rng(103)
+    if scene_name == "scene_0":
+        fs = ca.scene_0()
+    elif scene_name == "rtiow":
+        fs = ca.scene_rtiow(1)
+    else:
+        # duplicate objects: equal t for two list entries -> the later entry must win (src/caster.c:114,204)
+        base = ca.scene_0()
+        objs = np.concatenate([base.objects, base.objects[1:2], base.objects[3:4], base.objects[2:3]])
+        mats = np.concatenate([base.materials, base.materials[:1]])
+        objs = objs.copy()
+        objs["material"][4] = 4   # duplicate of the glass sphere with another material
+        objs["material"][5] = 0   # duplicate of the rect
+        objs["material"][6] = 1   # duplicate of the third sphere, after a rect in list order
+        fs = ca.FlatScene(objs, mats, [])
+    gpu.upload_scene(fs)
+    sc = orc.Scene.from_flat(fs)
+    n = 4000
+    rays = random_rays(rng, n)
+    # aim at objects of the scene
+    pick = rng.integers(0, len(fs.objects), size=n)
+    tgt = fs.objects["g"][pick, :3] + rng.normal(size=(n, 3)).astype(np.float32) * 0.6
+    aimed = rng.random(n) < 0.8
+    rays[aimed, 3:] = (tgt - rays[:, :3])[aimed]
+    g = gpu.test_hit_list(rays, strict=True)
+    o = orc.hit_list(sc, rays)
+    assert np.array_equal(g["hit"], o["hit"])
+    h = o["hit"] == 1
+    assert h.mean() > 0.5
+    assert np.array_equal(g["mat"][h], o["mat"][h])
+    assert np.array_equal(g["face"][h], o["face"][h])
+    assert np.array_equal(g["t"][h], o["t"][h])
+    assert np.array_equal(g["p"][h], o["p"][h])
+    assert np.array_equal(g["n"][h], o["n"][h])
+    if scene_name == "ties":
+        assert (o["mat"][h] == 4).any() and not (o["mat"][h] == 1).all()
+
+
+def _scatter_inputs(rng, ca, n):
+    mats = np.zeros(4, ca.MATERIAL_DTYPE)
+    mats["type"] = [0, 1, 2, 1]
+    mats["color0"] = [[0.5, 0.5, 0.5], [0.8, 0.7, 0.6], [0, 0, 0], [0.9, 0.9, 0.9]]
+    mats["fuzziness"] = [0, 0.3, 0, 0.0]
+    mats["n_refract"] = [0, 0, 1.5, 0]
+    mats["image"] = -1
+    objs = np.zeros(1, ca.OBJECT_DTYPE)
+    objs["g"][0, :4] = [0, 0, 0, 1]
+    fs = ca.FlatScene(objs, mats, [])
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32) * rng.uniform(0.1, 10, size=(n, 1)).astype(np.float32)
+    # incoming direction opposes the (face-corrected) normal, as hit_record_set_face guarantees
+    flip = (d * nrm).sum(axis=1) > 0
+    d[flip] = -d[flip]
+    # some grazing directions so that total internal reflection occurs for back-face dielectric hits
+    graze = rng.random(n) < 0.3
+    d[graze] -= (0.97 * (d[graze] * nrm[graze]).sum(axis=1, keepdims=True) * nrm[graze]).astype(np.float32)
+    p = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    rays = np.concatenate([p - d, d], axis=1).astype(np.float32)
+    face = rng.integers(0, 2, size=n).astype(np.int32)
+    mat = rng.integers(0, 4, size=n).astype(np.int32)
+    return fs, rays, p, nrm, face, mat
+
+
+def test_scatter_parity(gpu, orc, ca):
+    rng = np.random.default_rng(104)
+    n = 8000
+    fs, rays, p, nrm, face, mat = _scatter_inputs(rng, ca, n)
+    gpu.upload_scene(fs)
+    sc = orc.Scene.from_flat(fs)
+    g = gpu.test_scatter(rays, p, nrm, face, mat, seed=77, strict=True)
+    o = orc.scatter(sc, rays, p, nrm, face, mat, seed=77)
+    # the number of random draws is part of the contract (metal always draws, dielectric only when not TIR)
+    assert np.array_equal(g["draws"], o["draws"])
+    assert np.array_equal(g["ok"], o["ok"])
+    assert set(np.unique(o["draws"][mat == 2])) == {0, 1}
+    assert scaled_ulp(g["ray"][:, 3:], o["ray"][:, 3:], np.abs(o["ray"][:, 3:]).max(axis=1, keepdims=True)).max() <= ULP_TOL
+    assert np.array_equal(g["ray"][:, :3], o["ray"][:, :3])
+    # lambertian and metal use only +,-,*,/ and sqrt -> identical bits
+    lm = mat != 2
+    assert np.array_equal(g["ray"][lm], o["ray"][lm])
+    # dielectric: identical except where the Schlick term's powf rounding decides the branch
+    dm = mat == 2
+    same = np.all(g["ray"][dm] == o["ray"][dm], axis=1)
+    assert same.mean() > 0.999
+
+
+def test_camera_ray_parity(gpu, orc, ca):
+    rng = np.random.default_rng(105)
+    cam = ca.default_camera()
+    uv = rng.uniform(0, 1, size=(5000, 2)).astype(np.float32)
+    g = gpu.test_camera_ray(cam, uv, seed=5, strict=True)
+    o = orc.camera_ray(cam, uv, seed=5)
+    assert np.array_equal(g["draws"], o["draws"])
+    assert (o["draws"] % 2 == 0).all() and o["draws"].max() > 2
+    assert np.array_equal(g["ray"], o["ray"])
+
+
+def test_texture_parity(gpu, orc, ca):
+    rng = np.random.default_rng(106)
+    fs = ca.scene_0(textured=True)
+    gpu.upload_scene(fs)
+    sc = orc.Scene.from_flat(fs)
+    n = 6000
+    mat = rng.choice([0, 2], size=n).astype(np.int32)      # checker ground, image globe
+    uv = rng.uniform(-0.1, 1.1, size=(n, 2)).astype(np.float32)
+    uv[:10] = [[0, 0], [1, 1], [1, 0], [0, 1], [0.5, 0.5], [0.999999, 0.999999], [-1, 2], [2, -1], [1e-9, 1e-9], [0.25, 0.75]]
+    p = rng.uniform(-20, 20, size=(n, 3)).astype(np.float32)
+    g = gpu.test_texture(mat, uv, p, strict=True)
+    o = orc.texture(sc, mat, uv, p)
+    img = mat == 2
+    assert np.array_equal(g[img], o[img])
+    # the checker picks a colour by the sign of a product of sines: equal except on a sign tie
+    chk = mat == 0
+    assert (np.all(g[chk] == o[chk], axis=1)).mean() > 0.9995
+
+
+def test_fast_mode_functions_close(gpu, orc, ca):
+    """The fast arithmetic mode (FMA allowed) stays within a few ULP on well-conditioned inputs."""
+    rng = np.random.default_rng(107)
+    sph, rays, tr = _sphere_cases(rng, 4000)
+    small = sph[:, 3] < 10
+    g = gpu.test_hit_sphere(sph[small], rays[small], tr[small], strict=False)
+    o = orc.hit_sphere(sph[small], rays[small], tr[small])
+    agree = g["hit"] == o["hit"]
+    assert agree.mean() > 0.995
+    h = agree & (o["hit"] == 1)
+    rel = np.abs(g["t"][h] - o["t"][h]) / np.maximum(np.abs(o["t"][h]), 1e-3)
+    assert np.median(rel) < 1e-6 and np.quantile(rel, 0.99) < 1e-3

@@ -1,0 +1,136 @@
+"""Whole-image parity of the HIP path with the CPU restatement on the shared counter RNG.
+
+Bar (BASELINE north_star): with the same random stream images agree pixel for pixel within
+1e-4 relative error (strict arithmetic mode); ray counts are integers and must be equal.
+The only arithmetic difference by design is the order of the throughput product: the
+reference multiplies c1*(c2*(...*emit)) on the way out of its recursion, the iterative
+kernel ((c1*c2)*...)*emit, a last-ulp effect per path.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+
+
+def _assert_image_close(g, o, spp):
+    assert g.shape == o.shape
+    assert np.array_equal(g[..., 3], o[..., 3])                       # sample counts
+    assert np.all(o[..., 3] == spp)
+    err = np.abs(g[..., :3].astype(np.float64) - o[..., :3].astype(np.float64))
+    tol = REL_TOL * np.abs(o[..., :3].astype(np.float64)) + 1e-7
+    bad = err > tol
+    assert not bad.any(), f"{bad.sum()} channel values differ by more than {REL_TOL} relative; max err {err.max()}"
+
+
+SCENES = {
+    "scene_0": dict(make=lambda ca: ca.scene_0(), w=96, h=54, spp=24, depth=50, seed=0xC0FFEE),
+    "scene_0_textured": dict(make=lambda ca: ca.scene_0(textured=True), w=80, h=45, spp=16, depth=50, seed=11),
+    "rtiow": dict(make=lambda ca: ca.scene_rtiow(1), w=64, h=36, spp=8, depth=50, seed=3),
+    "rtiow_depth3": dict(make=lambda ca: ca.scene_rtiow(1), w=48, h=27, spp=8, depth=3, seed=4),
+    "stress_1500": dict(make=lambda ca: ca.scene_stress(1500, 2), w=40, h=24, spp=4, depth=50, seed=5),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_strict_image_matches_oracle(gpu, orc, ca, name):
+    cfg = SCENES[name]
+    fs = cfg["make"](ca)
+    cam = ca.default_camera(cfg["w"] / cfg["h"])
+    gpu.upload_scene(fs)
+    g, g_rays, _ = gpu.render_image(cam, cfg["w"], cfg["h"], cfg["spp"], cfg["depth"], cfg["seed"], strict=True)
+    o, o_rays = orc.render(orc.Scene.from_flat(fs), cam, cfg["w"], cfg["h"], cfg["spp"], cfg["depth"], cfg["seed"])
+    assert g_rays == o_rays
+    _assert_image_close(g, o, cfg["spp"])
+    # pixel store: identical bytes after the resolve
+    acc = gpu.malloc(g.nbytes)
+    try:
+        gpu.upload(acc, g)
+        rgba = gpu.resolve(acc, cfg["w"], cfg["h"], cfg["spp"])
+    finally:
+        gpu.free(acc)
+    assert np.array_equal(rgba, orc.resolve(g, cfg["spp"]))
+    assert (np.abs(rgba.astype(int) - orc.resolve(o, cfg["spp"]).astype(int)) <= 1).all()
+
+
+def test_odd_sizes_and_chunks(gpu, orc, ca):
+    """Frame sizes that are not multiples of the 8x8 pixel tile, sample counts that are not
+    multiples of the work-unit size; the unit size must not change any path."""
+    fs = ca.scene_0()
+    gpu.upload_scene(fs)
+    sc = orc.Scene.from_flat(fs)
+    w, h, spp, depth, seed = 37, 21, 11, 20, 9
+    cam = ca.default_camera(w / h)
+    o, o_rays = orc.render(sc, cam, w, h, spp, depth, seed)
+    ref = None
+    for chunk in (1, 4, 7, 64):
+        gpu.set_chunk(chunk)
+        g, rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
+        assert rays == o_rays
+        _assert_image_close(g, o, spp)
+        if chunk == 64:
+            ref = g
+    gpu.set_chunk(0)
+    g2, _, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
+    assert np.array_equal(g2, ref)          # bit-reproducible run to run
+
+
+def test_sample_partitions_sum_to_the_frame(gpu, orc, ca):
+    """Per-GPU sample partitions [g*spp/G, (g+1)*spp/G): same paths, sums add up."""
+    fs = ca.scene_rtiow(1)
+    gpu.upload_scene(fs)
+    w, h, spp, depth, seed = 48, 27, 10, 50, 21
+    cam = ca.default_camera(w / h)
+    whole, rays_whole, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
+    for G in (2, 3, 4):
+        acc = np.zeros_like(whole)
+        rays = 0
+        for r in range(G):
+            s0, s1 = spp * r // G, spp * (r + 1) // G
+            part, pr, _ = gpu.render_image(cam, w, h, s1 - s0, depth, seed, strict=True, sample_begin=s0)
+            acc += part
+            rays += pr
+        assert rays == rays_whole
+        assert np.allclose(acc[..., :3], whole[..., :3], rtol=2e-6, atol=1e-7)
+        assert np.array_equal(acc[..., 3], whole[..., 3])
+
+
+def test_empty_and_degenerate_inputs(gpu, ca):
+    fs = ca.scene_0()
+    gpu.upload_scene(fs)
+    cam = ca.default_camera(16 / 9)
+    s, rays, _ = gpu.render_image(cam, 16, 9, 0, 50, 1, strict=True)          # zero samples
+    assert rays == 0 and not s.any()
+    s, rays, _ = gpu.render_image(cam, 16, 9, 4, 0, 1, strict=True)           # depth 0: black, no rays (src/caster.c:436)
+    assert rays == 0 and not s[..., :3].any() and np.all(s[..., 3] == 4)
+    empty = ca.FlatScene(np.zeros(0, ca.OBJECT_DTYPE), np.zeros(0, ca.MATERIAL_DTYPE), [])
+    gpu.upload_scene(empty)                                                    # empty hit_list: every ray misses
+    s, rays, _ = gpu.render_image(cam, 16, 9, 3, 50, 1, strict=True)
+    assert rays == 16 * 9 * 3 and not s[..., :3].any()
+    with pytest.raises(ca.CasterHipError):
+        bad = fs.objects.copy()
+        bad["material"][0] = 99
+        gpu.upload_scene(ca.FlatScene(bad, fs.materials, []))
+    with pytest.raises(ca.CasterHipError):
+        bad = fs.objects.copy()
+        bad["type"][0] = 2          # xz rect: declared, never defined in the reference
+        gpu.upload_scene(ca.FlatScene(bad, fs.materials, []))
+
+
+def test_fast_mode_statistically_equal(gpu, orc, ca):
+    """Fast arithmetic (FMA, reordered ops) renders the same image up to Monte-Carlo noise: at
+    equal seeds almost every path is identical, so the images are far closer than the
+    PSNR > 45 dB / mean-abs-error < 1/255 bar that BASELINE sets against unmodified CRaytracer."""
+    fs = ca.scene_rtiow(1)
+    gpu.upload_scene(fs)
+    w, h, spp, depth, seed = 96, 54, 64, 50, 1234
+    cam = ca.default_camera(w / h)
+    s, rs, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
+    f, rf, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=False)
+    a = np.sqrt(np.clip(s[..., :3] / spp, 0, None)).clip(0, 1)
+    b = np.sqrt(np.clip(f[..., :3] / spp, 0, None)).clip(0, 1)
+    mae = np.abs(a - b).mean()
+    psnr = 10 * np.log10(1.0 / max(np.mean((a - b) ** 2), 1e-12))
+    assert abs(rs - rf) / rs < 5e-3
+    assert mae < 1 / 255 and psnr > 45, (mae, psnr)
