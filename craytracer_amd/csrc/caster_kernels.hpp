@@ -12,10 +12,6 @@
 
 namespace caster {
 
-constexpr int kBlock = 256;       // 4 waves
-constexpr int kSphTile = 1024;    // spheres staged in LDS at a time (16 KiB)
-constexpr int kTileW = 8, kTileH = 8;
-
 static_assert(sizeof(MatRec) == sizeof(Mat), "material record layout");
 static_assert(sizeof(ImgRec) == sizeof(Img), "image record layout");
 static_assert(sizeof(CamRec) == sizeof(Cam), "camera record layout");
@@ -44,6 +40,12 @@ CDEV Cam cam_of(const CamRec& c)
     return k;
 }
 
+}  // namespace caster
+
+#include "caster_render.hpp"
+
+namespace caster {
+
 // Closest hit of the rect list, merged into the result of the sphere loop.
 // best_ord is the list position of the current winner; an equal t goes to the
 // later list entry, which is what the reference's in-order loop produces.
@@ -59,168 +61,6 @@ CDEV void closest_rects(const SceneView& sc, const Ray& r, float& closest, int& 
             }
         }
     }
-}
-
-// Camera ray for sample s of pixel (i, j): src/dispatcher.c:21-24.
-CDEV void start_path(const Cam& cam, int width, int height, int i, int j, int s, uint32_t seed,
-                     Rng& g, Ray& r)
-{
-    rng_seed(g, seed, (uint32_t)(j * width + i), (uint32_t)s);
-    float u = ((float)i + random_f32(g)) / (float)(width - 1);
-    float v = ((float)j + random_f32(g)) / (float)(height - 1);
-    r = ray_from_cam(cam, g, u, v);
-}
-
-// One wave owns an 8x8 pixel tile and one chunk of the sample range; a lane
-// owns one pixel and walks its samples in order, starting the next camera ray
-// as soon as a path ends.  Every loop trip tests the lane's current ray
-// against the whole sphere list, staged through LDS in tiles of kSphTile.
-__global__ __launch_bounds__(kBlock)
-void CASTER_NAME(render_kernel_)(RenderArgs a)
-{
-    __shared__ float4 s_sph[kSphTile];
-
-    const SceneView sc = view_of(a.scene);
-    const Cam cam = cam_of(a.cam);
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int tiles_x = (a.width + kTileW - 1) / kTileW;
-    const int tiles_y = (a.height + kTileH - 1) / kTileH;
-    const int n_tiles = tiles_x * tiles_y;
-    const int unit = blockIdx.x * (kBlock / 64) + wave;
-    const int chunk = unit / n_tiles;
-    const int tile = unit - chunk * n_tiles;
-    const int i = (tile % tiles_x) * kTileW + (lane & 7);
-    const int j = (tile / tiles_x) * kTileH + (lane >> 3);
-    const bool valid = (chunk < a.n_chunks) && (i < a.width) && (j < a.height);
-    const int s0 = a.s_begin + chunk * a.chunk;
-    const int s_end = a.s_begin + a.s_count;
-    const int s1 = (s0 + a.chunk < s_end) ? s0 + a.chunk : s_end;
-
-    const bool tiled = sc.n_sph > kSphTile;
-    if (!tiled) {
-        for (int k = threadIdx.x; k < sc.n_sph; k += kBlock) {
-            float4 s = sc.sph[k];
-            s.w = s.w * s.w;
-            s_sph[k] = s;
-        }
-        __syncthreads();
-    }
-
-    V3 sum = mk(0.0f, 0.0f, 0.0f);
-    int s = s0;
-    bool alive = valid && (s < s1) && (a.max_depth > 0);
-    Ray r;
-    r.o = mk(0.0f, 0.0f, 0.0f);
-    r.d = mk(0.0f, 0.0f, 1.0f);
-    V3 thr = mk(1.0f, 1.0f, 1.0f);
-    int depth = a.max_depth;
-    Rng g;
-    g.s = 0; g.draws = 0;
-    unsigned int rays = 0;
-    if (alive) start_path(cam, a.width, a.height, i, j, s, a.seed, g, r);
-
-    for (;;) {
-        const bool any_alive = tiled ? (__syncthreads_or(alive ? 1 : 0) != 0) : (__any(alive ? 1 : 0) != 0);
-        if (!any_alive) break;
-
-        float closest = kTMax;
-        int best_sph = -1;
-        const float aa = dot(r.d, r.d);
-        if (!tiled) {
-            if (alive) {
-                for (int k = 0; k < sc.n_sph; ++k) {
-                    float root;
-                    if (sphere_root(s_sph[k], r.o, r.d, aa, kTMin, closest, root)) {
-                        closest = root; best_sph = k;
-                    }
-                }
-            }
-        } else {
-            for (int base = 0; base < sc.n_sph; base += kSphTile) {
-                const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
-                __syncthreads();
-                for (int k = threadIdx.x; k < cnt; k += kBlock) {
-                    float4 sp = sc.sph[base + k];
-                    sp.w = sp.w * sp.w;
-                    s_sph[k] = sp;
-                }
-                __syncthreads();
-                if (alive) {
-                    for (int k = 0; k < cnt; ++k) {
-                        float root;
-                        if (sphere_root(s_sph[k], r.o, r.d, aa, kTMin, closest, root)) {
-                            closest = root; best_sph = base + k;
-                        }
-                    }
-                }
-            }
-        }
-
-        if (alive) {
-            rays++;
-            int best_ord = (best_sph >= 0) ? sc.sph_meta[best_sph].x : -1;
-            int best_rect = -1;
-            closest_rects(sc, r, closest, best_ord, best_rect);
-
-            bool cont = false;
-            V3 radiance = mk(0.0f, 0.0f, 0.0f);
-            if (best_ord >= 0) {
-                HitRec rec;
-                if (best_rect >= 0) {
-                    finish_rect(rec, r, closest, sc.rect_a[best_rect], sc.rect_b[best_rect],
-                                sc.rect_meta[best_rect].y);
-                } else {
-                    const float4 sp = sc.sph[best_sph];
-                    finish_sphere(rec, r, closest, mk(sp.x, sp.y, sp.z), sp.w, sc.sph_meta[best_sph].y);
-                }
-                Ray next;
-                V3 atten, emit;
-                cont = shade(sc, g, r, rec, next, atten, emit);
-                if (cont) {
-                    thr = thr * atten;
-                    r = next;
-                    depth--;
-                    if (depth <= 0) cont = false;   // ray_color(depth 0) is black, uncounted
-                } else {
-                    radiance = thr * emit;
-                }
-            }
-            if (!cont) {
-                sum = sum + radiance;
-                s++;
-                if (s < s1) {
-                    start_path(cam, a.width, a.height, i, j, s, a.seed, g, r);
-                    thr = mk(1.0f, 1.0f, 1.0f);
-                    depth = a.max_depth;
-                } else {
-                    alive = false;
-                }
-            }
-        }
-    }
-
-    if (valid) {
-        const int done = (s1 > s0) ? (s1 - s0) : 0;
-        a.slabs[(size_t)chunk * a.width * a.height + (size_t)j * a.width + i] =
-            make_float4(sum.x, sum.y, sum.z, (float)done);
-    }
-
-    // one ray-count atomic per wave
-    unsigned int wrays = rays;
-    for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
-    if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
-}
-
-hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a, hipStream_t st)
-{
-    const int tiles_x = (a.width + kTileW - 1) / kTileW;
-    const int tiles_y = (a.height + kTileH - 1) / kTileH;
-    const long long units = (long long)tiles_x * tiles_y * a.n_chunks;
-    const long long blocks = (units + (kBlock / 64) - 1) / (kBlock / 64);
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(CASTER_NAME(render_kernel_), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
-    return hipGetLastError();
 }
 
 // ------------------------------------------------------------ test kernels --

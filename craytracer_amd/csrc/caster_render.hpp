@@ -1,0 +1,399 @@
+// The path-tracing kernel.  Replaces the recursion of ray_color
+// (src/caster.c:425-491) and the per-pixel sample loop of job_func
+// (src/dispatcher.c:12-30) by an iterative loop over a pool of paths.
+//
+// Work decomposition
+//   * a work unit is an 8x8 pixel tile times a chunk of the sample range; one
+//     wave owns one unit, a 256-thread block holds four waves that share one
+//     copy of the sphere list in LDS;
+//   * every lane carries TWO path slots, so a wave traces 128 rays per loop
+//     trip and the sphere test runs on packed FP32 (v_pk_*_f32: slot A in the
+//     low half, slot B in the high half), one LDS broadcast read per sphere;
+//   * when a path ends, its radiance is added to the tile's accumulator in LDS
+//     and the slot takes the next (pixel, sample) of the unit's pool: the
+//     finished slots are found with a ballot and numbered with mbcnt, so the
+//     wave stays full until the pool is empty;
+//   * the unit's sums go to a slab private to its chunk; a later kernel adds
+//     the slabs in chunk order (no float atomics in global memory, renders are
+//     bit-reproducible).
+//
+// Every ray is tested against every sphere (src/caster.c:204 has no early
+// out): the loop computes the discriminant for both slots branch-free and
+// enters the root/closest-hit code only when some lane has a candidate.
+#pragma once
+
+#include "caster_device.hpp"
+#include "caster_launch.h"
+
+namespace caster {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBlock = 256;                 // 4 waves
+constexpr int kWaves = kBlock / 64;
+constexpr int kSphTile = 1024;              // spheres staged in LDS at a time (16 KiB)
+constexpr int kTileW = 8, kTileH = 8;       // pixels per work unit
+
+CDEV f2 splat(float x) { return f2{x, x}; }
+
+struct Slot {
+    V3 o, d;        // strict: d as the reference has it; fast: unit length
+    float aa;       // strict: d.d ; fast: 1
+    float tmin;     // strict: 0.001 ; fast: 0.001 * |d|
+    float tmax;     // strict: 16777215 ; fast: 16777215 * |d|
+    V3 thr;         // product of the attenuations so far
+    Rng g;
+    int q;          // pixel of the tile this path belongs to (0..63)
+    int depth;      // rays this path may still shoot
+    bool alive;
+};
+
+// A slot without a path: a ray that starts far outside any scene and misses
+// every sphere with a finite negative discriminant, so it never takes the
+// candidate branch.
+CDEV void park(Slot& s)
+{
+    s.o = mk(0.0f, 1.0e15f, 0.0f);
+    s.d = mk(1.0f, 0.0f, 0.0f);
+    s.aa = 1.0f;
+    s.tmin = kTMin;
+    s.tmax = kTMax;
+    s.alive = false;
+}
+
+CDEV void set_ray(Slot& s, const Ray& r)
+{
+    s.o = r.o;
+#if CASTER_STRICT
+    s.d = r.d;
+    s.aa = dot(r.d, r.d);
+    s.tmin = kTMin;
+    s.tmax = kTMax;
+#else
+    // t is measured along the unit direction: t' = t * |d|
+    const float len2 = dot(r.d, r.d);
+    const float inv = __frsqrt_rn(len2);
+    const float len = len2 * inv;
+    s.d = r.d * inv;
+    s.aa = 1.0f;
+    s.tmin = kTMin * len;
+    s.tmax = kTMax * len;
+#endif
+}
+
+struct TileGeom {
+    int x0, y0;     // pixel of the tile's corner
+    int tw, th;     // valid pixels (partial tiles at the right / top edge)
+};
+
+// Camera ray for pool entry m of the unit: src/dispatcher.c:21-24.
+CDEV void start_pool_path(Slot& s, int m, const TileGeom& tg, int s0, const RenderArgs& a, const Cam& cam)
+{
+    const int nvalid = tg.tw * tg.th;
+    int smp, qx, qy;
+    if (nvalid == 64) {
+        smp = m >> 6; qx = m & 7; qy = (m >> 3) & 7;
+    } else {
+        smp = m / nvalid;
+        const int rem = m - smp * nvalid;
+        qy = rem / tg.tw;
+        qx = rem - qy * tg.tw;
+    }
+    const int i = tg.x0 + qx, j = tg.y0 + qy;
+    rng_seed(s.g, a.seed, (uint32_t)(j * a.width + i), (uint32_t)(s0 + smp));
+    const float u = ((float)i + random_f32(s.g)) / (float)(a.width - 1);
+    const float v = ((float)j + random_f32(s.g)) / (float)(a.height - 1);
+    const Ray r = ray_from_cam(cam, s.g, u, v);
+    set_ray(s, r);
+    s.thr = mk(1.0f, 1.0f, 1.0f);
+    s.q = qy * kTileW + qx;
+    s.depth = a.max_depth;
+    s.alive = true;
+}
+
+// Slots without a path take the next entries of the pool, in lane order.
+CDEV void refill(Slot& s, int& next, int total, const TileGeom& tg, int s0, const RenderArgs& a, const Cam& cam)
+{
+    if (next >= total) return;                       // wave-uniform
+    const unsigned long long want = __ballot(!s.alive);
+    if (want == 0ull) return;
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+    const int m = next + rank;
+    if (!s.alive && m < total) start_pool_path(s, m, tg, s0, a, cam);
+    next += __popcll(want);
+}
+
+// LDS image of one sphere: {cx, cy, r*r, cz}.  The order puts each value where
+// a packed instruction can broadcast it to both halves without a register move.
+CDEV float4 lds_sphere(const float4 s /* cx, cy, cz, r */) { return make_float4(s.x, s.y, s.w * s.w, s.z); }
+// Pads a tile to a multiple of kGroup: negative r*r far below any hb*hb, so the
+// discriminant is a finite negative number for every ray.
+CDEV float4 lds_pad_sphere() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
+
+constexpr int kGroup = 4;   // spheres per software-pipeline stage
+
+struct Disc { f2 hb, disc; };
+
+// Discriminant of one sphere for both slots (src/caster.c:101-105).
+CDEV Disc sphere_disc(const float4 s, f2 ox, f2 oy, f2 oz, f2 dx, f2 dy, f2 dz, f2 aa)
+{
+    Disc r;
+    const f2 ocx = ox - splat(s.x);
+    const f2 ocy = oy - splat(s.y);
+    const f2 ocz = oz - splat(s.w);
+#if CASTER_STRICT
+    r.hb = (ocx * dx + ocy * dy) + ocz * dz;
+    const f2 c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - splat(s.z);
+    r.disc = r.hb * r.hb - aa * c;
+#else
+    (void)aa;
+    f2 hb = ocx * dx;
+    hb = __builtin_elementwise_fma(ocy, dy, hb);
+    hb = __builtin_elementwise_fma(ocz, dz, hb);
+    f2 c = __builtin_elementwise_fma(ocx, ocx, -splat(s.z));
+    c = __builtin_elementwise_fma(ocy, ocy, c);
+    c = __builtin_elementwise_fma(ocz, ocz, c);
+    r.hb = hb;
+    r.disc = __builtin_elementwise_fma(hb, hb, -c);
+#endif
+    return r;
+}
+
+// Root selection and closest-hit update for one sphere with a candidate in
+// some lane (src/caster.c:107-121, 209-214).
+CDEV void sphere_accept(const float4 s, const Disc& dd, int index, const Slot& sa, const Slot& sb,
+                        float& closestA, float& closestB, int& bestA, int& bestB)
+{
+#if CASTER_STRICT
+    (void)dd;
+    const float4 ref = make_float4(s.x, s.y, s.w, s.z);   // sphere_root wants {cx, cy, cz, r*r}
+    float root;
+    if (sphere_root(ref, sa.o, sa.d, sa.aa, sa.tmin, closestA, root)) { closestA = root; bestA = index; }
+    if (sphere_root(ref, sb.o, sb.d, sb.aa, sb.tmin, closestB, root)) { closestB = root; bestB = index; }
+#else
+    (void)s;
+    if (dd.disc.x >= 0.0f) {
+        const float sq = __builtin_amdgcn_sqrtf(dd.disc.x);
+        float root = -dd.hb.x - sq;
+        if (root < sa.tmin || root > closestA) root = -dd.hb.x + sq;
+        if (!(root < sa.tmin || root > closestA)) { closestA = root; bestA = index; }
+    }
+    if (dd.disc.y >= 0.0f) {
+        const float sq = __builtin_amdgcn_sqrtf(dd.disc.y);
+        float root = -dd.hb.y - sq;
+        if (root < sb.tmin || root > closestB) root = -dd.hb.y + sq;
+        if (!(root < sb.tmin || root > closestB)) { closestB = root; bestB = index; }
+    }
+#endif
+}
+
+CDEV bool any_candidate(const Disc& dd)
+{
+#if CASTER_STRICT
+    return !(dd.disc.x < 0.0f) || !(dd.disc.y < 0.0f);     // a NaN discriminant is a candidate, as in the reference
+#else
+    return fmaxf(dd.disc.x, dd.disc.y) >= 0.0f;
+#endif
+}
+
+// Sphere loop over one LDS tile for the two slots of a lane.  cnt is a
+// multiple of kGroup (the tile is padded).  The next group's spheres are read
+// from LDS before the current group's discriminants are evaluated, so the read
+// latency overlaps arithmetic.  closest / best are updated exactly as the
+// reference's in-order loop does (src/caster.c:204-215).
+CDEV void isect_tile(const float4* lds, int cnt, int base, const Slot& sa, const Slot& sb,
+                     float& closestA, float& closestB, int& bestA, int& bestB)
+{
+    const f2 ox = f2{sa.o.x, sb.o.x}, oy = f2{sa.o.y, sb.o.y}, oz = f2{sa.o.z, sb.o.z};
+    const f2 dx = f2{sa.d.x, sb.d.x}, dy = f2{sa.d.y, sb.d.y}, dz = f2{sa.d.z, sb.d.z};
+    const f2 aa = f2{sa.aa, sb.aa};
+    float4 cur[kGroup];
+#pragma unroll
+    for (int j = 0; j < kGroup; ++j) cur[j] = lds[j];
+#pragma unroll 1
+    for (int k = 0; k < cnt; k += kGroup) {
+        float4 nxt[kGroup];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) nxt[j] = lds[k + kGroup + j];   // the tile has kGroup entries of slack
+        Disc dd[kGroup];
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) dd[j] = sphere_disc(cur[j], ox, oy, oz, dx, dy, dz, aa);
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+            if (any_candidate(dd[j]))
+                sphere_accept(cur[j], dd[j], base + k + j, sa, sb, closestA, closestB, bestA, bestB);
+        }
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) cur[j] = nxt[j];
+    }
+}
+
+// Copies spheres [base, base+cnt) into LDS and pads to a multiple of kGroup
+// plus one group of slack for the loop's read-ahead.  Returns the padded count.
+CDEV int stage_spheres(float4* lds, const float4* sph, int base, int cnt)
+{
+    const int padded = (cnt + kGroup - 1) / kGroup * kGroup;
+    for (int k = threadIdx.x; k < padded + kGroup; k += kBlock)
+        lds[k] = (k < cnt) ? lds_sphere(sph[base + k]) : lds_pad_sphere();
+    return padded;
+}
+
+// After the sphere loop: merge the rects, build the hit record, shade, and
+// either continue the path or end it (adding its radiance to the tile).
+CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, float* tile_acc, unsigned int& rays)
+{
+    if (!s.alive) return;
+    rays++;
+    Ray r;
+    r.o = s.o;
+    r.d = s.d;
+    int best_ord = (best_sph >= 0) ? sc.sph_meta[best_sph].x : -1;
+    int best_rect = -1;
+    for (int k = 0; k < sc.n_rect; ++k) {
+        float t;
+        if (rect_root(sc.rect_a[k], sc.rect_b[k], r, s.tmin, closest, t)) {
+            const int ord = sc.rect_meta[k].x;
+            if (t < closest || ord > best_ord || best_ord < 0) { closest = t; best_ord = ord; best_rect = k; }
+        }
+    }
+
+    bool cont = false;
+    V3 radiance = mk(0.0f, 0.0f, 0.0f);
+    if (best_ord >= 0) {
+        HitRec rec;
+        if (best_rect >= 0) {
+            finish_rect(rec, r, closest, sc.rect_a[best_rect], sc.rect_b[best_rect], sc.rect_meta[best_rect].y);
+        } else {
+            const float4 sp = sc.sph[best_sph];
+            finish_sphere(rec, r, closest, mk(sp.x, sp.y, sp.z), sp.w, sc.sph_meta[best_sph].y);
+        }
+        Ray next;
+        V3 atten, emit;
+        cont = shade(sc, s.g, r, rec, next, atten, emit);
+        if (cont) {
+            s.thr = s.thr * atten;
+            set_ray(s, next);
+            s.depth--;
+            if (s.depth <= 0) cont = false;          // ray_color at depth 0 is black and is not counted
+        } else {
+            radiance = s.thr * emit;
+        }
+    }
+    if (!cont) {
+        atomicAdd(&tile_acc[s.q * 3 + 0], radiance.x);
+        atomicAdd(&tile_acc[s.q * 3 + 1], radiance.y);
+        atomicAdd(&tile_acc[s.q * 3 + 2], radiance.z);
+        park(s);
+    }
+}
+
+CDEV void swap_slots(Slot& a, Slot& b)
+{
+    Slot t = a;
+    a = b;
+    b = t;
+}
+
+template <bool TILED>
+__global__ __launch_bounds__(kBlock, 4)
+void CASTER_NAME(render_kernel_)(RenderArgs a)
+{
+    __shared__ float4 s_sph[kSphTile + 2 * kGroup];
+    __shared__ float s_acc[kWaves][kTileW * kTileH * 3];
+
+    const SceneView sc = view_of(a.scene);
+    const Cam cam = cam_of(a.cam);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int tiles_x = (a.width + kTileW - 1) / kTileW;
+    const int tiles_y = (a.height + kTileH - 1) / kTileH;
+    const int n_tiles = tiles_x * tiles_y;
+    const int unit = blockIdx.x * kWaves + wave;
+    const int chunk = unit / n_tiles;
+    const int tile = unit - chunk * n_tiles;
+    const bool has_unit = chunk < a.n_chunks;
+    TileGeom tg;
+    tg.x0 = (tile % tiles_x) * kTileW;
+    tg.y0 = (tile / tiles_x) * kTileH;
+    tg.tw = (a.width - tg.x0 < kTileW) ? a.width - tg.x0 : kTileW;
+    tg.th = (a.height - tg.y0 < kTileH) ? a.height - tg.y0 : kTileH;
+    const int s0 = a.s_begin + chunk * a.chunk;
+    const int s_end = a.s_begin + a.s_count;
+    const int cs = has_unit ? ((s0 + a.chunk < s_end) ? a.chunk : s_end - s0) : 0;
+    const int total = (a.max_depth > 0) ? tg.tw * tg.th * cs : 0;
+
+    float* tile_acc = s_acc[wave];
+    for (int k = lane; k < kTileW * kTileH * 3; k += 64) tile_acc[k] = 0.0f;
+    int n_lds = 0;
+    if (!TILED) n_lds = stage_spheres(s_sph, sc.sph, 0, sc.n_sph);
+    __syncthreads();
+
+    Slot sa, sb;
+    sa.thr = sb.thr = mk(1.0f, 1.0f, 1.0f);
+    sa.g.s = sb.g.s = 0; sa.g.draws = sb.g.draws = 0;
+    sa.q = sb.q = 0; sa.depth = sb.depth = 0;
+    park(sa);
+    park(sb);
+    int next = 0;
+    unsigned int rays = 0;
+
+    for (;;) {
+        refill(sa, next, total, tg, s0, a, cam);
+        refill(sb, next, total, tg, s0, a, cam);
+        const int live = (sa.alive || sb.alive) ? 1 : 0;
+        const bool any_live = TILED ? (__syncthreads_or(live) != 0) : (__any(live) != 0);
+        if (!any_live) break;
+
+        float closestA = sa.tmax, closestB = sb.tmax;
+        int bestA = -1, bestB = -1;
+        if (!TILED) {
+            isect_tile(s_sph, n_lds, 0, sa, sb, closestA, closestB, bestA, bestB);
+        } else {
+            for (int base = 0; base < sc.n_sph; base += kSphTile) {
+                const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
+                if (base) __syncthreads();           // everyone is done with the previous tile
+                const int padded = stage_spheres(s_sph, sc.sph, base, cnt);
+                __syncthreads();
+                isect_tile(s_sph, padded, base, sa, sb, closestA, closestB, bestA, bestB);
+            }
+        }
+
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {
+            bounce(sa, closestA, bestA, sc, tile_acc, rays);
+            swap_slots(sa, sb);
+            float tf = closestA; closestA = closestB; closestB = tf;
+            int ti = bestA; bestA = bestB; bestB = ti;
+        }
+    }
+
+    if (has_unit) {
+        // lane l writes pixel l of the tile
+        const int qx = lane & 7, qy = lane >> 3;
+        if (qx < tg.tw && qy < tg.th) {
+            const size_t px = (size_t)(tg.y0 + qy) * a.width + (tg.x0 + qx);
+            a.slabs[(size_t)chunk * a.width * a.height + px] =
+                make_float4(tile_acc[lane * 3 + 0], tile_acc[lane * 3 + 1], tile_acc[lane * 3 + 2], (float)cs);
+        }
+    }
+
+    unsigned int wrays = rays;
+    for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
+    if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
+}
+
+hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a, hipStream_t st)
+{
+    const int tiles_x = (a.width + kTileW - 1) / kTileW;
+    const int tiles_y = (a.height + kTileH - 1) / kTileH;
+    const long long units = (long long)tiles_x * tiles_y * a.n_chunks;
+    const long long blocks = (units + kWaves - 1) / kWaves;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (a.scene.n_sph > kSphTile)
+        hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<true>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    else
+        hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<false>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace caster

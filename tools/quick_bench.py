@@ -1,0 +1,52 @@
+"""Developer timing loop: renders one scene on cuda:0 in either arithmetic mode and prints
+Mrays/s and the fraction of the FP32 VALU peak (157.3 TFLOP/s)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import craytracer_amd as ca  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="rtiow")
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--spp", type=int, default=32)
+ap.add_argument("--depth", type=int, default=50)
+ap.add_argument("--chunk", type=int, default=0)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--modes", default="fast,strict")
+args = ap.parse_args()
+
+if args.scene == "rtiow":
+    fs = ca.scene_rtiow(1)
+elif args.scene == "scene_0":
+    fs = ca.scene_0()
+elif args.scene.startswith("stress:"):
+    fs = ca.scene_stress(int(args.scene.split(":")[1]), 2)
+else:
+    raise SystemExit("unknown scene")
+ns, nr = fs.n_spheres, fs.n_rects
+gpu = ca.CasterHip(0)
+gpu.upload_scene(fs)
+if args.chunk:
+    gpu.set_chunk(args.chunk)
+cam = ca.default_camera(args.width / args.height)
+nbytes = args.width * args.height * 16
+acc = gpu.malloc(nbytes)
+for mode in args.modes.split(","):
+    strict = mode == "strict"
+    for rep in range(args.reps):
+        gpu.memset_zero(acc, nbytes)
+        gpu.synchronize()
+        t0 = time.perf_counter()
+        gpu.render(cam, args.width, args.height, 0, args.spp, args.depth, 0xC0FFEE, acc, strict=strict)
+        rays, ms = gpu.render_stats()
+        wall = time.perf_counter() - t0
+        flops = rays * (18 * ns + 12 * nr + 100)
+        print(f"{mode:6s} rep{rep} rays {rays} ({rays / (args.width * args.height * args.spp):.2f}/path) kernel {ms:.2f} ms wall {wall * 1e3:.2f} ms "
+              f"{rays / ms * 1e-3:.1f} Mrays/s  {flops / (ms * 1e-3) / 157.3e12 * 100:.1f}% of FP32 peak", flush=True)
+gpu.free(acc)

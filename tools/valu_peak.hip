@@ -62,7 +62,7 @@ int main()
     printf("device: %s, CUs %d, clock %d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
     float* d_out;
     hipMalloc(&d_out, sizeof(float) * 256 * 32 * 1024);
-    const int iters = 20000;
+    const int iters = 400000;
     constexpr int ILP = 8;
     for (int wps : {1, 2, 4, 8}) {           // waves per SIMD
         const int threads = 256;             // 4 waves per block -> 1 per SIMD
