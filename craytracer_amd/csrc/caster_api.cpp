@@ -331,7 +331,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
         return CASTER_HIP_OK;
     }
 
-    int chunk = ctx->chunk > 0 ? ctx->chunk : 64;
+    int chunk = ctx->chunk > 0 ? ctx->chunk : 128;
     if (chunk > sample_count) chunk = sample_count;
     const int n_chunks = (sample_count + chunk - 1) / chunk;
     const size_t n_pixels = (size_t)width * height;

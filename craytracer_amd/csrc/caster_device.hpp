@@ -377,13 +377,22 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
     const Mat m = sc.mats[rec.m];
     emit = mk(0.0f, 0.0f, 0.0f);
     atten = mk(1.0f, 1.0f, 1.0f);
+    // Lambertian and metal both start with one unit-sphere rejection sample and
+    // nothing else is drawn before it (material.c:6,17), so the sampling loop is
+    // shared: the wave runs it once for the lanes of both materials.
+    V3 us = mk(0.0f, 0.0f, 0.0f);
+    if (m.type == 0 || m.type == 1) us = random_unit_sphere(g);
     switch (m.type) {
-    case 0: // MTYPE_LAMBERTIAN
-        scatter_lambertian(g, rec, next);
+    case 0: // MTYPE_LAMBERTIAN, material.c:3-12
+        next.o = rec.p;
+        next.d = rec.n + to_unit(us);
+        if (near_zero(next.d)) next.d = rec.n;
         atten = texture_color(sc, m, rec);
         return true;
-    case 1: // MTYPE_METAL
-        if (scatter_metal(g, r, rec, m.fuzz, next)) {
+    case 1: // MTYPE_METAL, material.c:14-19
+        next.o = rec.p;
+        next.d = reflect(to_unit(r.d), rec.n) + us * m.fuzz;
+        if (dot(next.d, rec.n) > 0.0f) {
             atten = texture_color(sc, m, rec);
             return true;
         }

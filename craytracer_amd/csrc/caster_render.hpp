@@ -336,16 +336,28 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     park(sb);
     int next = 0;
     unsigned int rays = 0;
+    float closestA = kTMax, closestB = kTMax;
+    int bestA = -1, bestB = -1;
 
     for (;;) {
-        refill(sa, next, total, tg, s0, a, cam);
-        refill(sb, next, total, tg, s0, a, cam);
+        // One copy of the per-slot code serves both slots (the slots trade places
+        // after each turn), so a path computes the same values in either slot.
+        // On the first trip both slots are parked: bounce() does nothing and
+        // refill() starts the first 128 paths.
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {
+            bounce(sa, closestA, bestA, sc, tile_acc, rays);
+            refill(sa, next, total, tg, s0, a, cam);
+            swap_slots(sa, sb);
+            float tf = closestA; closestA = closestB; closestB = tf;
+            int ti = bestA; bestA = bestB; bestB = ti;
+        }
         const int live = (sa.alive || sb.alive) ? 1 : 0;
         const bool any_live = TILED ? (__syncthreads_or(live) != 0) : (__any(live) != 0);
         if (!any_live) break;
 
-        float closestA = sa.tmax, closestB = sb.tmax;
-        int bestA = -1, bestB = -1;
+        closestA = sa.tmax; closestB = sb.tmax;
+        bestA = -1; bestB = -1;
         if (!TILED) {
             isect_tile(s_sph, n_lds, 0, sa, sb, closestA, closestB, bestA, bestB);
         } else {
@@ -356,14 +368,6 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
                 __syncthreads();
                 isect_tile(s_sph, padded, base, sa, sb, closestA, closestB, bestA, bestB);
             }
-        }
-
-#pragma unroll 1
-        for (int k = 0; k < 2; ++k) {
-            bounce(sa, closestA, bestA, sc, tile_acc, rays);
-            swap_slots(sa, sb);
-            float tf = closestA; closestA = closestB; closestB = tf;
-            int ti = bestA; bestA = bestB; bestB = ti;
         }
     }
 
