@@ -46,6 +46,7 @@ struct Cam { V3 o, llc, h, v, u0, v0; float lr; };
 struct SceneView {
     const float4* sph;      // cx, cy, cz, r
     const int2*   sph_meta; // list position, material
+    const float4* sph_filter;
     const float4* rect_a;   // cx, cy, cz, du
     const float4* rect_b;   // dv, -, -, -
     const int2*   rect_meta;
@@ -65,35 +66,44 @@ CDEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y + a.z * b.z); }      
 CDEV V3 to_unit(V3 v) { return v / sqrtf(dot(v, v)); }                          // common.c:89-97
 
 // ------------------------------------------------------------------ RNG --
-// Replaces rand() (src/common.c:10-13).  The stream for one path is keyed by
-// (seed, pixel, sample): SplitMix64 of the key gives the start state of a
-// PCG-XSH-RR 64/32 generator; a draw is its top 24 bits, random_f32 = n/2^24.
-struct Rng { uint64_t s; uint32_t draws; };
+// Replaces rand() (src/common.c:10-13).  One xoshiro128+ stream per path: the
+// four state words are a chain of 32-bit avalanche hashes of (seed, pixel,
+// sample); a draw is the top 24 bits of the output, random_f32 = n / 2^24.
+// A draw costs nine full-rate integer ops and no multiply, which matters
+// because the rejection samplers make the wave pay for its slowest lane.
+struct Rng { uint32_t s0, s1, s2, s3; uint32_t draws; };
 
-CDEV uint64_t mix64(uint64_t z)
+CDEV uint32_t mix32(uint32_t x)
 {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
 }
 
 CDEV void rng_seed(Rng& g, uint32_t seed, uint32_t pixel, uint32_t sample)
 {
-    uint64_t z = ((uint64_t)pixel << 32) | (uint64_t)sample;
-    z ^= (uint64_t)seed * 0x9E3779B97F4A7C15ull;
-    g.s = mix64(z);
+    const uint32_t a = mix32(pixel ^ mix32(seed + 0x9E3779B9u));
+    const uint32_t b = mix32(sample + a);
+    const uint32_t c = mix32(b + 0x9E3779B9u);
+    const uint32_t d = mix32(c + 0x9E3779B9u);
+    g.s0 = a; g.s1 = b; g.s2 = c; g.s3 = d | 1u;
     g.draws = 0;
 }
 
 CDEV uint32_t rng_next24(Rng& g)
 {
-    uint64_t old = g.s;
-    g.s = old * 6364136223846793005ull + 1442695040888963407ull;
-    uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
-    uint32_t rot = (uint32_t)(old >> 59);
-    uint32_t out = (xs >> rot) | (xs << ((32u - rot) & 31u));
-    return out >> 8;
+    const uint32_t result = g.s0 + g.s3;
+    const uint32_t t = g.s1 << 9;
+    g.s2 ^= g.s0;
+    g.s3 ^= g.s1;
+    g.s1 ^= g.s2;
+    g.s0 ^= g.s3;
+    g.s2 ^= t;
+    g.s3 = (g.s3 << 11) | (g.s3 >> 21);
+    return result >> 8;
 }
 
 CDEV float random_f32(Rng& g)                                   // common.c:10-13

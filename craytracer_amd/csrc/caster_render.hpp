@@ -123,118 +123,199 @@ CDEV void refill(Slot& s, int& next, int total, const TileGeom& tg, int s0, cons
     next += __popcll(want);
 }
 
-// LDS image of one sphere: {cx, cy, r*r, cz}.  The order puts each value where
-// a packed instruction can broadcast it to both halves without a register move.
-CDEV float4 lds_sphere(const float4 s /* cx, cy, cz, r */) { return make_float4(s.x, s.y, s.w * s.w, s.z); }
-// Pads a tile to a multiple of kGroup: negative r*r far below any hb*hb, so the
-// discriminant is a finite negative number for every ray.
-CDEV float4 lds_pad_sphere() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
-
-constexpr int kGroup = 4;   // spheres per software-pipeline stage
-
-struct Disc { f2 hb, disc; };
-
-// Discriminant of one sphere for both slots (src/caster.c:101-105).
-CDEV Disc sphere_disc(const float4 s, f2 ox, f2 oy, f2 oz, f2 dx, f2 dy, f2 dz, f2 aa)
-{
-    Disc r;
-    const f2 ocx = ox - splat(s.x);
-    const f2 ocy = oy - splat(s.y);
-    const f2 ocz = oz - splat(s.w);
+// ---- sphere loop ---------------------------------------------------------
+// LDS holds two images of the sphere tile:
+//   exact[k]  = {cx, cy, r*r, cz}: the operands of the reference's test
+//               (src/caster.c:101-105).  The order puts each value where a
+//               packed instruction can broadcast it to both halves of a
+//               register pair without a move.
+//   filter[k] = {cx-Px, cy-Py, g*(C+r*r)-(C-r*r), cz-Pz}, fast mode only, with
+//               C = |c-P|^2 and P a reference point near the scene's spheres.
+// The strict loop evaluates the reference's discriminant, in its operation
+// order, for both slots of the lane with packed arithmetic and runs the scalar
+// reference test only where a lane has a discriminant that is not negative.
+// The fast loop first evaluates the expanded form
+//   hb*hb - |o-c|^2 + r*r = (hb*hb - |o'|^2) + (2 o'.c' - (C - r*r)),  o' = o-P, c' = c-P,
+// which needs no per-sphere subtraction (8 packed ops instead of 10), plus a
+// margin g*(|o'|^2 + C + r*r) that exceeds its rounding error, and evaluates
+// the direct form only for the candidates that pass.
 #if CASTER_STRICT
-    r.hb = (ocx * dx + ocy * dy) + ocz * dz;
-    const f2 c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - splat(s.z);
-    r.disc = r.hb * r.hb - aa * c;
+constexpr int kGroup = 2;               // spheres per software-pipeline stage (the strict candidate code needs the registers)
 #else
-    (void)aa;
-    f2 hb = ocx * dx;
-    hb = __builtin_elementwise_fma(ocy, dy, hb);
-    hb = __builtin_elementwise_fma(ocz, dz, hb);
-    f2 c = __builtin_elementwise_fma(ocx, ocx, -splat(s.z));
-    c = __builtin_elementwise_fma(ocy, ocy, c);
-    c = __builtin_elementwise_fma(ocz, ocz, c);
-    r.hb = hb;
-    r.disc = __builtin_elementwise_fma(hb, hb, -c);
+constexpr int kGroup = 4;
+#endif
+constexpr int kLdsSlack = 2 * kGroup;   // read-ahead beyond the padded tile
+constexpr float kFilterMargin = 2.5e-6f;
+
+CDEV float4 exact_image(const float4 s /* cx, cy, cz, r */) { return make_float4(s.x, s.y, s.w * s.w, s.z); }
+// Pad entries: r*r = -1e30 gives a finite negative discriminant for every ray.
+CDEV float4 exact_pad() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
+CDEV float4 filter_pad() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
+
+struct SphereLds {
+    const float4* exact;
+    const float4* filter;
+};
+
+struct PairRays {     // both slots of a lane, packed
+    f2 ox, oy, oz, dx, dy, dz, aa;        // strict operands
+    f2 p2x, p2y, p2z, ndx, ndy, ndz, od, base;   // fast filter operands
+};
+
+CDEV PairRays pack_rays(const Slot& sa, const Slot& sb, const float3 ref)
+{
+    PairRays r;
+    r.ox = f2{sa.o.x, sb.o.x}; r.oy = f2{sa.o.y, sb.o.y}; r.oz = f2{sa.o.z, sb.o.z};
+    r.dx = f2{sa.d.x, sb.d.x}; r.dy = f2{sa.d.y, sb.d.y}; r.dz = f2{sa.d.z, sb.d.z};
+    r.aa = f2{sa.aa, sb.aa};
+#if !CASTER_STRICT
+    const f2 qx = r.ox - splat(ref.x), qy = r.oy - splat(ref.y), qz = r.oz - splat(ref.z);
+    const f2 oo = qx * qx + qy * qy + qz * qz;
+    r.od = qx * r.dx + qy * r.dy + qz * r.dz;
+    r.p2x = qx + qx; r.p2y = qy + qy; r.p2z = qz + qz;
+    r.ndx = -r.dx; r.ndy = -r.dy; r.ndz = -r.dz;
+    r.base = oo * splat(kFilterMargin - 1.0f);
+#else
+    (void)ref;
 #endif
     return r;
 }
 
-// Root selection and closest-hit update for one sphere with a candidate in
-// some lane (src/caster.c:107-121, 209-214).
-CDEV void sphere_accept(const float4 s, const Disc& dd, int index, const Slot& sa, const Slot& sb,
-                        float& closestA, float& closestB, int& bestA, int& bestB)
+// Per sphere: the value whose sign decides whether the sphere is a candidate.
+CDEV f2 candidate_key(const PairRays& r, const float4 e, const float4 f)
 {
 #if CASTER_STRICT
-    (void)dd;
-    const float4 ref = make_float4(s.x, s.y, s.w, s.z);   // sphere_root wants {cx, cy, cz, r*r}
-    float root;
-    if (sphere_root(ref, sa.o, sa.d, sa.aa, sa.tmin, closestA, root)) { closestA = root; bestA = index; }
-    if (sphere_root(ref, sb.o, sb.d, sb.aa, sb.tmin, closestB, root)) { closestB = root; bestB = index; }
+    (void)f;
+    const f2 ocx = r.ox - splat(e.x);
+    const f2 ocy = r.oy - splat(e.y);
+    const f2 ocz = r.oz - splat(e.w);
+    const f2 hb = (ocx * r.dx + ocy * r.dy) + ocz * r.dz;
+    const f2 c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - splat(e.z);
+    return hb * hb - r.aa * c;
 #else
-    (void)s;
-    if (dd.disc.x >= 0.0f) {
-        const float sq = __builtin_amdgcn_sqrtf(dd.disc.x);
-        float root = -dd.hb.x - sq;
-        if (root < sa.tmin || root > closestA) root = -dd.hb.x + sq;
-        if (!(root < sa.tmin || root > closestA)) { closestA = root; bestA = index; }
-    }
-    if (dd.disc.y >= 0.0f) {
-        const float sq = __builtin_amdgcn_sqrtf(dd.disc.y);
-        float root = -dd.hb.y - sq;
-        if (root < sb.tmin || root > closestB) root = -dd.hb.y + sq;
-        if (!(root < sb.tmin || root > closestB)) { closestB = root; bestB = index; }
+    (void)e;
+    f2 hb = __builtin_elementwise_fma(r.ndz, splat(f.w), r.od);
+    hb = __builtin_elementwise_fma(r.ndy, splat(f.y), hb);
+    hb = __builtin_elementwise_fma(r.ndx, splat(f.x), hb);
+    f2 t2 = __builtin_elementwise_fma(r.p2z, splat(f.w), splat(f.z));
+    t2 = __builtin_elementwise_fma(r.p2y, splat(f.y), t2);
+    t2 = __builtin_elementwise_fma(r.p2x, splat(f.x), t2);
+    return __builtin_elementwise_fma(hb, hb, r.base) + t2;
+#endif
+}
+
+CDEV bool any_candidate(const f2 key)
+{
+#if CASTER_STRICT
+    return !(key.x < 0.0f) || !(key.y < 0.0f);     // a NaN discriminant is a candidate, as in the reference
+#else
+    return fmaxf(key.x, key.y) >= 0.0f;
+#endif
+}
+
+// Root selection and closest-hit update for one slot (src/caster.c:107-121, 209-214).
+CDEV void accept_one(const float4 e /* cx, cy, r*r, cz */, int index, const Slot& s, float& closest, int& best)
+{
+#if CASTER_STRICT
+    float root;
+    if (sphere_root(make_float4(e.x, e.y, e.w, e.z), s.o, s.d, s.aa, s.tmin, closest, root)) { closest = root; best = index; }
+#else
+    const float ocx = s.o.x - e.x, ocy = s.o.y - e.y, ocz = s.o.z - e.w;
+    const float hb = ocx * s.d.x + ocy * s.d.y + ocz * s.d.z;
+    const float c = ocx * ocx + ocy * ocy + ocz * ocz - e.z;
+    const float disc = hb * hb - c;                       // the direction has unit length
+    if (disc >= 0.0f) {
+        const float sq = __builtin_amdgcn_sqrtf(disc);
+        float root = -hb - sq;
+        if (root < s.tmin || root > closest) root = -hb + sq;
+        if (!(root < s.tmin || root > closest)) { closest = root; best = index; }
     }
 #endif
 }
 
-CDEV bool any_candidate(const Disc& dd)
+// One sphere whose operands g are already in registers (strict: the exact
+// image; fast: the filter image); k is its position in the LDS tile.
+CDEV void process_sphere(const float4 g, const SphereLds& lds, int k, int index, const PairRays& r,
+                         const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
+    const f2 key = candidate_key(r, g, g);
+    if (any_candidate(key)) {
 #if CASTER_STRICT
-    return !(dd.disc.x < 0.0f) || !(dd.disc.y < 0.0f);     // a NaN discriminant is a candidate, as in the reference
+        (void)lds; (void)k;
+        accept_one(g, index, sa, closestA, bestA);
+        accept_one(g, index, sb, closestB, bestB);
 #else
-    return fmaxf(dd.disc.x, dd.disc.y) >= 0.0f;
+        const float4 e = lds.exact[k];
+        if (key.x >= 0.0f) accept_one(e, index, sa, closestA, bestA);
+        if (key.y >= 0.0f) accept_one(e, index, sb, closestB, bestB);
+#endif
+    }
+}
+
+// A pipeline stage: kGroup spheres held in named registers (no indexed array,
+// so nothing can end up in scratch memory).
+struct Group {
+    float4 g0, g1;
+#if !CASTER_STRICT
+    float4 g2, g3;
+#endif
+};
+
+CDEV Group load_group(const float4* src, int k)
+{
+    Group g;
+    g.g0 = src[k]; g.g1 = src[k + 1];
+#if !CASTER_STRICT
+    g.g2 = src[k + 2]; g.g3 = src[k + 3];
+#endif
+    return g;
+}
+
+CDEV void process_group(const Group& g, const SphereLds& lds, int k, int index, const PairRays& r,
+                        const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
+{
+    process_sphere(g.g0, lds, k, index, r, sa, sb, closestA, closestB, bestA, bestB);
+    process_sphere(g.g1, lds, k + 1, index + 1, r, sa, sb, closestA, closestB, bestA, bestB);
+#if !CASTER_STRICT
+    process_sphere(g.g2, lds, k + 2, index + 2, r, sa, sb, closestA, closestB, bestA, bestB);
+    process_sphere(g.g3, lds, k + 3, index + 3, r, sa, sb, closestA, closestB, bestA, bestB);
 #endif
 }
 
 // Sphere loop over one LDS tile for the two slots of a lane.  cnt is a
-// multiple of kGroup (the tile is padded).  The next group's spheres are read
-// from LDS before the current group's discriminants are evaluated, so the read
-// latency overlaps arithmetic.  closest / best are updated exactly as the
+// multiple of 2*kGroup (the tile is padded) and kLdsSlack entries beyond it are
+// readable.  Two register sets alternate: while one group is evaluated the
+// next one is already on its way from LDS.  closest / best are updated as the
 // reference's in-order loop does (src/caster.c:204-215).
-CDEV void isect_tile(const float4* lds, int cnt, int base, const Slot& sa, const Slot& sb,
+CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, const Slot& sa, const Slot& sb,
                      float& closestA, float& closestB, int& bestA, int& bestB)
 {
-    const f2 ox = f2{sa.o.x, sb.o.x}, oy = f2{sa.o.y, sb.o.y}, oz = f2{sa.o.z, sb.o.z};
-    const f2 dx = f2{sa.d.x, sb.d.x}, dy = f2{sa.d.y, sb.d.y}, dz = f2{sa.d.z, sb.d.z};
-    const f2 aa = f2{sa.aa, sb.aa};
-    float4 cur[kGroup];
-#pragma unroll
-    for (int j = 0; j < kGroup; ++j) cur[j] = lds[j];
+#if CASTER_STRICT
+    const float4* src = lds.exact;
+#else
+    const float4* src = lds.filter;
+#endif
+    Group ga = load_group(src, 0);
 #pragma unroll 1
-    for (int k = 0; k < cnt; k += kGroup) {
-        float4 nxt[kGroup];
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) nxt[j] = lds[k + kGroup + j];   // the tile has kGroup entries of slack
-        Disc dd[kGroup];
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) dd[j] = sphere_disc(cur[j], ox, oy, oz, dx, dy, dz, aa);
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) {
-            if (any_candidate(dd[j]))
-                sphere_accept(cur[j], dd[j], base + k + j, sa, sb, closestA, closestB, bestA, bestB);
-        }
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) cur[j] = nxt[j];
+    for (int k = 0; k < cnt; k += 2 * kGroup) {
+        const Group gb = load_group(src, k + kGroup);
+        process_group(ga, lds, k, base + k, r, sa, sb, closestA, closestB, bestA, bestB);
+        ga = load_group(src, k + 2 * kGroup);
+        process_group(gb, lds, k + kGroup, base + k + kGroup, r, sa, sb, closestA, closestB, bestA, bestB);
     }
 }
 
-// Copies spheres [base, base+cnt) into LDS and pads to a multiple of kGroup
-// plus one group of slack for the loop's read-ahead.  Returns the padded count.
-CDEV int stage_spheres(float4* lds, const float4* sph, int base, int cnt)
+// Copies spheres [base, base+cnt) into LDS, padded to a multiple of 2*kGroup
+// plus the read-ahead slack.  Returns the padded count.
+CDEV int stage_spheres(float4* exact, float4* filter, const SceneView& sc, int base, int cnt)
 {
-    const int padded = (cnt + kGroup - 1) / kGroup * kGroup;
-    for (int k = threadIdx.x; k < padded + kGroup; k += kBlock)
-        lds[k] = (k < cnt) ? lds_sphere(sph[base + k]) : lds_pad_sphere();
+    const int padded = (cnt + 2 * kGroup - 1) / (2 * kGroup) * (2 * kGroup);
+    for (int k = threadIdx.x; k < padded + kLdsSlack; k += kBlock) {
+        exact[k] = (k < cnt) ? exact_image(sc.sph[base + k]) : exact_pad();
+#if !CASTER_STRICT
+        filter[k] = (k < cnt) ? sc.sph_filter[base + k] : filter_pad();
+#endif
+    }
     return padded;
 }
 
@@ -298,7 +379,12 @@ template <bool TILED>
 __global__ __launch_bounds__(kBlock, 4)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
-    __shared__ float4 s_sph[kSphTile + 2 * kGroup];
+    __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
+#if !CASTER_STRICT
+    __shared__ float4 s_filter[kSphTile + 2 * kLdsSlack];
+#else
+    float4* s_filter = s_exact;
+#endif
     __shared__ float s_acc[kWaves][kTileW * kTileH * 3];
 
     const SceneView sc = view_of(a.scene);
@@ -325,12 +411,17 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     float* tile_acc = s_acc[wave];
     for (int k = lane; k < kTileW * kTileH * 3; k += 64) tile_acc[k] = 0.0f;
     int n_lds = 0;
-    if (!TILED) n_lds = stage_spheres(s_sph, sc.sph, 0, sc.n_sph);
+    if (!TILED) n_lds = stage_spheres(s_exact, s_filter, sc, 0, sc.n_sph);
+    SphereLds lds;
+    lds.exact = s_exact;
+    lds.filter = s_filter;
+    const float3 ref = make_float3(a.scene.ref[0], a.scene.ref[1], a.scene.ref[2]);
     __syncthreads();
 
     Slot sa, sb;
     sa.thr = sb.thr = mk(1.0f, 1.0f, 1.0f);
-    sa.g.s = sb.g.s = 0; sa.g.draws = sb.g.draws = 0;
+    sa.g.s0 = sa.g.s1 = sa.g.s2 = sa.g.s3 = sa.g.draws = 0;
+    sb.g = sa.g;
     sa.q = sb.q = 0; sa.depth = sb.depth = 0;
     park(sa);
     park(sb);
@@ -358,15 +449,16 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
 
         closestA = sa.tmax; closestB = sb.tmax;
         bestA = -1; bestB = -1;
+        const PairRays pr = pack_rays(sa, sb, ref);
         if (!TILED) {
-            isect_tile(s_sph, n_lds, 0, sa, sb, closestA, closestB, bestA, bestB);
+            isect_tile(lds, n_lds, 0, pr, sa, sb, closestA, closestB, bestA, bestB);
         } else {
             for (int base = 0; base < sc.n_sph; base += kSphTile) {
                 const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
                 if (base) __syncthreads();           // everyone is done with the previous tile
-                const int padded = stage_spheres(s_sph, sc.sph, base, cnt);
+                const int padded = stage_spheres(s_exact, s_filter, sc, base, cnt);
                 __syncthreads();
-                isect_tile(s_sph, padded, base, sa, sb, closestA, closestB, bestA, bestB);
+                isect_tile(lds, padded, base, pr, sa, sb, closestA, closestB, bestA, bestB);
             }
         }
     }

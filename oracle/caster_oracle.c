@@ -19,42 +19,51 @@
 /*
  * The reference draws from libc rand() (src/common.c:10-13), seeded from the
  * wall clock, so its images are not reproducible.  Mode ORC_RNG_COUNTER is the
- * replacement the HIP path shares: a PCG-XSH-RR 64/32 stream whose start state
- * is a SplitMix64 hash of (seed, pixel, sample); one draw is the top 24 bits,
- * so random_f32 = n / 2^24 lies in [0, 1) and is exact in binary32.
+ * replacement the HIP path shares: one xoshiro128+ stream per path, whose four
+ * state words are a chain of 32-bit avalanche hashes of (seed, pixel, sample);
+ * one draw is the top 24 bits of the generator's output, so
+ * random_f32 = n / 2^24 lies in [0, 1) and is exact in binary32.
  */
-static uint64_t orc_mix64(uint64_t z)
+static uint32_t orc_mix32(uint32_t x)
 {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
 }
 
 void orc_rng_seed(orng* g, uint32_t seed, uint32_t pixel, uint32_t sample)
 {
-    uint64_t z = ((uint64_t)pixel << 32) | (uint64_t)sample;
-    z ^= (uint64_t)seed * 0x9E3779B97F4A7C15ull;
-    g->state = orc_mix64(z);
+    const uint32_t a = orc_mix32(pixel ^ orc_mix32(seed + 0x9E3779B9u));
+    const uint32_t b = orc_mix32(sample + a);
+    const uint32_t c = orc_mix32(b + 0x9E3779B9u);
+    const uint32_t d = orc_mix32(c + 0x9E3779B9u);
+    g->s[0] = a; g->s[1] = b; g->s[2] = c; g->s[3] = d | 1u;
     g->draws = 0;
     g->mode = ORC_RNG_COUNTER;
 }
 
 void orc_rng_libc(orng* g)
 {
-    g->state = 0;
+    g->s[0] = g->s[1] = g->s[2] = g->s[3] = 0;
     g->draws = 0;
     g->mode = ORC_RNG_LIBC;
 }
 
 uint32_t orc_rng_next24(orng* g)
 {
-    uint64_t old = g->state;
-    g->state = old * 6364136223846793005ull + 1442695040888963407ull;
-    uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
-    uint32_t rot = (uint32_t)(old >> 59);
-    uint32_t out = (xs >> rot) | (xs << ((32u - rot) & 31u));
-    return out >> 8;
+    uint32_t* s = g->s;
+    const uint32_t result = s[0] + s[3];
+    const uint32_t t = s[1] << 9;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = (s[3] << 11) | (s[3] >> 21);
+    return result >> 8;
 }
 
 /* src/common.c:10-13 */

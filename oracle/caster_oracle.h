@@ -88,7 +88,7 @@ typedef struct {        /* inc/camera.h:6-13 */
  * mode 1: libc rand() exactly as src/common.c:10-13 (not thread safe). */
 enum { ORC_RNG_COUNTER = 0, ORC_RNG_LIBC = 1 };
 typedef struct {
-    uint64_t state;
+    uint32_t s[4];
     uint64_t draws;
     int32_t mode;
     int32_t pad;
