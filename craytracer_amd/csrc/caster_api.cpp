@@ -247,10 +247,12 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
         imgs[k].w = images[k].w; imgs[k].h = images[k].h; imgs[k].bpp = images[k].bpp; imgs[k].pad = 0;
     }
 
-    // Fast-mode candidate filter (see caster_render.hpp): reference point P = mean
-    // centre of the ordinary spheres; a sphere much larger than the median one is
-    // always a candidate (its entry is +inf).
+    // Candidate filter tables (see caster_render.hpp): reference point P = mean
+    // centre of the ordinary spheres; per sphere c' = c - P, K = |c'|^2 - r*r and
+    // the error scale |c'|^2 + r*r.  A sphere much larger than the median one
+    // gets K = -inf: it is always a candidate.
     std::vector<float4> sph_filter(sph.size());
+    std::vector<float> sph_scale(sph.size());
     double ref[3] = {0.0, 0.0, 0.0};
     if (!sph.empty()) {
         std::vector<float> radii;
@@ -262,15 +264,14 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
             if (fabs((double)q.w) <= huge_r) { ref[0] += q.x; ref[1] += q.y; ref[2] += q.z; ++n_ord; }
         if (n_ord) { ref[0] /= (double)n_ord; ref[1] /= (double)n_ord; ref[2] /= (double)n_ord; }
         const float pf[3] = {(float)ref[0], (float)ref[1], (float)ref[2]};
-        const double g = 2.5e-6;   // == kFilterMargin
         for (size_t k = 0; k < sph.size(); ++k) {
             const float4 q = sph[k];
             const float cx = q.x - pf[0], cy = q.y - pf[1], cz = q.z - pf[2];
             const double C = (double)cx * cx + (double)cy * cy + (double)cz * cz;
             const double r2 = (double)q.w * (double)q.w;
-            const bool huge = fabs((double)q.w) > huge_r || !std::isfinite(C) || !std::isfinite(r2);
-            const float nk = huge ? INFINITY : (float)(g * (C + r2) - (C - r2));
-            sph_filter[k] = make_float4(cx, cy, nk, cz);
+            const bool huge = !(fabs((double)q.w) <= huge_r) || !std::isfinite(C) || !std::isfinite(r2);
+            sph_filter[k] = make_float4(cx, cy, cz, huge ? -INFINITY : (float)(C - r2));
+            sph_scale[k] = huge ? 0.0f : (float)(C + r2);
         }
         ref[0] = pf[0]; ref[1] = pf[1]; ref[2] = pf[2];
     }
@@ -279,6 +280,7 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
     int rc;
     if ((rc = upload_array(ctx, sph, &s.sph))) return rc;
     if ((rc = upload_array(ctx, sph_filter, &s.sph_filter))) return rc;
+    if ((rc = upload_array(ctx, sph_scale, &s.sph_scale))) return rc;
     s.ref[0] = (float)ref[0]; s.ref[1] = (float)ref[1]; s.ref[2] = (float)ref[2];
     if ((rc = upload_array(ctx, sph_meta, &s.sph_meta))) return rc;
     if ((rc = upload_array(ctx, rect_a, &s.rect_a))) return rc;

@@ -23,14 +23,15 @@ struct CamRec { float o[3], llc[3], h[3], v[3], u0[3], v0[3]; float lr; };
 struct SceneDev {
     const float4* sph;       // cx, cy, cz, r            (list order among spheres)
     const int2*   sph_meta;  // list position, material
-    const float4* sph_filter;// fast mode: cx-Px, cy-Py, g*(C+r*r)-(C-r*r), cz-Pz  (C = |c-P|^2)
+    const float4* sph_filter;// candidate filter: cx-Px, cy-Py, cz-Pz, C - r*r   (C = |c-P|^2; -inf = always a candidate)
+    const float*  sph_scale; // C + r*r, the scale of the filter's rounding error
     const float4* rect_a;    // cx, cy, cz, du
     const float4* rect_b;    // dv, 0, 0, 0
     const int2*   rect_meta;
     const MatRec* mats;
     const ImgRec* imgs;
     int n_sph, n_rect, n_mat, n_img;
-    float ref[3];            // P, the reference point of the fast-mode filter
+    float ref[3];            // P, the reference point of the candidate filter
 };
 
 struct RenderArgs {

@@ -125,75 +125,78 @@ CDEV void refill(Slot& s, int& next, int total, const TileGeom& tg, int s0, cons
 
 // ---- sphere loop ---------------------------------------------------------
 // LDS holds two images of the sphere tile:
+//   filter[k] = {cx-Px, cy-Py, g*(C+r*r)-(C-r*r), cz-Pz}, with C = |c-P|^2 and
+//               P a reference point near the scene's spheres;
 //   exact[k]  = {cx, cy, r*r, cz}: the operands of the reference's test
-//               (src/caster.c:101-105).  The order puts each value where a
-//               packed instruction can broadcast it to both halves of a
-//               register pair without a move.
-//   filter[k] = {cx-Px, cy-Py, g*(C+r*r)-(C-r*r), cz-Pz}, fast mode only, with
-//               C = |c-P|^2 and P a reference point near the scene's spheres.
-// The strict loop evaluates the reference's discriminant, in its operation
-// order, for both slots of the lane with packed arithmetic and runs the scalar
-// reference test only where a lane has a discriminant that is not negative.
-// The fast loop first evaluates the expanded form
-//   hb*hb - |o-c|^2 + r*r = (hb*hb - |o'|^2) + (2 o'.c' - (C - r*r)),  o' = o-P, c' = c-P,
-// which needs no per-sphere subtraction (8 packed ops instead of 10), plus a
-// margin g*(|o'|^2 + C + r*r) that exceeds its rounding error, and evaluates
-// the direct form only for the candidates that pass.
+//               (src/caster.c:101-105).
+// The value order puts each operand where a packed instruction can broadcast
+// it to both halves of a register pair.
+//
+// Every ray meets every sphere (the reference has no early out), but only a
+// few spheres per ray can be hit.  The loop therefore evaluates, for both slots
+// of the lane at once, a conservative candidate test and runs the reference's
+// own arithmetic only for the candidates.  With unit direction u, o' = o-P and
+// c' = c-P the discriminant of src/caster.c:105 has the sign of
+//   hb*hb - |o-c|^2 + r*r = (hb*hb - |o'|^2) + (2 o'.c' - (C - r*r)),  hb = o'.u - c'.u,
+// which needs no per-sphere subtraction: 8 packed FP32 instructions per sphere
+// and lane pair.  The key adds a margin g*(|o'|^2 + C + r*r) that exceeds the
+// rounding error of both this form and the reference's form, so a sphere the
+// reference's test would accept is always a candidate; what the candidate code
+// then decides is exactly what the reference decides (strict mode) or the same
+// test on the unit direction (fast mode).  Spheres much larger than the rest
+// (ground, sky) carry +inf and are always candidates.
 #if CASTER_STRICT
 constexpr int kGroup = 2;               // spheres per software-pipeline stage (the strict candidate code needs the registers)
+constexpr float kFilterMargin = 1.0e-5f;
 #else
 constexpr int kGroup = 4;
+constexpr float kFilterMargin = 2.5e-6f;
 #endif
 constexpr int kLdsSlack = 2 * kGroup;   // read-ahead beyond the padded tile
-constexpr float kFilterMargin = 2.5e-6f;
 
 CDEV float4 exact_image(const float4 s /* cx, cy, cz, r */) { return make_float4(s.x, s.y, s.w * s.w, s.z); }
 // Pad entries: r*r = -1e30 gives a finite negative discriminant for every ray.
 CDEV float4 exact_pad() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
 CDEV float4 filter_pad() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
+// Host table entry {c'x, c'y, c'z, (C - r*r) | +inf for always, C + r*r in .w of a second table}: see filter_image.
+CDEV float4 filter_image(const float4 h /* c'x, c'y, c'z, K = C - r*r (or -inf) */, const float scale /* C + r*r */)
+{
+    return make_float4(h.x, h.y, kFilterMargin * scale - h.w, h.z);
+}
 
 struct SphereLds {
     const float4* exact;
     const float4* filter;
 };
 
-struct PairRays {     // both slots of a lane, packed
-    f2 ox, oy, oz, dx, dy, dz, aa;        // strict operands
-    f2 p2x, p2y, p2z, ndx, ndy, ndz, od, base;   // fast filter operands
+struct PairRays {     // filter operands of both slots of a lane, packed
+    f2 p2x, p2y, p2z, ndx, ndy, ndz, od, base;
 };
 
 CDEV PairRays pack_rays(const Slot& sa, const Slot& sb, const float3 ref)
 {
     PairRays r;
-    r.ox = f2{sa.o.x, sb.o.x}; r.oy = f2{sa.o.y, sb.o.y}; r.oz = f2{sa.o.z, sb.o.z};
-    r.dx = f2{sa.d.x, sb.d.x}; r.dy = f2{sa.d.y, sb.d.y}; r.dz = f2{sa.d.z, sb.d.z};
-    r.aa = f2{sa.aa, sb.aa};
-#if !CASTER_STRICT
-    const f2 qx = r.ox - splat(ref.x), qy = r.oy - splat(ref.y), qz = r.oz - splat(ref.z);
-    const f2 oo = qx * qx + qy * qy + qz * qz;
-    r.od = qx * r.dx + qy * r.dy + qz * r.dz;
-    r.p2x = qx + qx; r.p2y = qy + qy; r.p2z = qz + qz;
-    r.ndx = -r.dx; r.ndy = -r.dy; r.ndz = -r.dz;
-    r.base = oo * splat(kFilterMargin - 1.0f);
+    const f2 qx = f2{sa.o.x, sb.o.x} - splat(ref.x);
+    const f2 qy = f2{sa.o.y, sb.o.y} - splat(ref.y);
+    const f2 qz = f2{sa.o.z, sb.o.z} - splat(ref.z);
+#if CASTER_STRICT
+    // the slots keep the reference's unnormalised direction; the filter wants a unit one
+    const f2 inv = f2{__frsqrt_rn(sa.aa), __frsqrt_rn(sb.aa)};
+    const f2 ux = f2{sa.d.x, sb.d.x} * inv, uy = f2{sa.d.y, sb.d.y} * inv, uz = f2{sa.d.z, sb.d.z} * inv;
 #else
-    (void)ref;
+    const f2 ux = f2{sa.d.x, sb.d.x}, uy = f2{sa.d.y, sb.d.y}, uz = f2{sa.d.z, sb.d.z};
 #endif
+    const f2 oo = qx * qx + qy * qy + qz * qz;
+    r.od = qx * ux + qy * uy + qz * uz;
+    r.p2x = qx + qx; r.p2y = qy + qy; r.p2z = qz + qz;
+    r.ndx = -ux; r.ndy = -uy; r.ndz = -uz;
+    r.base = oo * splat(kFilterMargin - 1.0f);
     return r;
 }
 
 // Per sphere: the value whose sign decides whether the sphere is a candidate.
-CDEV f2 candidate_key(const PairRays& r, const float4 e, const float4 f)
+CDEV f2 candidate_key(const PairRays& r, const float4 f)
 {
-#if CASTER_STRICT
-    (void)f;
-    const f2 ocx = r.ox - splat(e.x);
-    const f2 ocy = r.oy - splat(e.y);
-    const f2 ocz = r.oz - splat(e.w);
-    const f2 hb = (ocx * r.dx + ocy * r.dy) + ocz * r.dz;
-    const f2 c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - splat(e.z);
-    return hb * hb - r.aa * c;
-#else
-    (void)e;
     f2 hb = __builtin_elementwise_fma(r.ndz, splat(f.w), r.od);
     hb = __builtin_elementwise_fma(r.ndy, splat(f.y), hb);
     hb = __builtin_elementwise_fma(r.ndx, splat(f.x), hb);
@@ -201,15 +204,14 @@ CDEV f2 candidate_key(const PairRays& r, const float4 e, const float4 f)
     t2 = __builtin_elementwise_fma(r.p2y, splat(f.y), t2);
     t2 = __builtin_elementwise_fma(r.p2x, splat(f.x), t2);
     return __builtin_elementwise_fma(hb, hb, r.base) + t2;
-#endif
 }
 
-CDEV bool any_candidate(const f2 key)
+CDEV bool is_candidate(float key)
 {
 #if CASTER_STRICT
-    return !(key.x < 0.0f) || !(key.y < 0.0f);     // a NaN discriminant is a candidate, as in the reference
+    return !(key < 0.0f);       // a NaN key (non-finite ray) is a candidate: the reference lets NaN through (caster.c:107)
 #else
-    return fmaxf(key.x, key.y) >= 0.0f;
+    return key >= 0.0f;
 #endif
 }
 
@@ -233,22 +235,16 @@ CDEV void accept_one(const float4 e /* cx, cy, r*r, cz */, int index, const Slot
 #endif
 }
 
-// One sphere whose operands g are already in registers (strict: the exact
-// image; fast: the filter image); k is its position in the LDS tile.
-CDEV void process_sphere(const float4 g, const SphereLds& lds, int k, int index, const PairRays& r,
+// One sphere whose filter operands f are already in registers; k is its
+// position in the LDS tile, index its position in the scene's sphere array.
+CDEV void process_sphere(const float4 f, const SphereLds& lds, int k, int index, const PairRays& r,
                          const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
-    const f2 key = candidate_key(r, g, g);
-    if (any_candidate(key)) {
-#if CASTER_STRICT
-        (void)lds; (void)k;
-        accept_one(g, index, sa, closestA, bestA);
-        accept_one(g, index, sb, closestB, bestB);
-#else
+    const f2 key = candidate_key(r, f);
+    if (is_candidate(key.x) || is_candidate(key.y)) {
         const float4 e = lds.exact[k];
-        if (key.x >= 0.0f) accept_one(e, index, sa, closestA, bestA);
-        if (key.y >= 0.0f) accept_one(e, index, sb, closestB, bestB);
-#endif
+        if (is_candidate(key.x)) accept_one(e, index, sa, closestA, bestA);
+        if (is_candidate(key.y)) accept_one(e, index, sb, closestB, bestB);
     }
 }
 
@@ -290,11 +286,7 @@ CDEV void process_group(const Group& g, const SphereLds& lds, int k, int index, 
 CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, const Slot& sa, const Slot& sb,
                      float& closestA, float& closestB, int& bestA, int& bestB)
 {
-#if CASTER_STRICT
-    const float4* src = lds.exact;
-#else
     const float4* src = lds.filter;
-#endif
     Group ga = load_group(src, 0);
 #pragma unroll 1
     for (int k = 0; k < cnt; k += 2 * kGroup) {
@@ -312,9 +304,7 @@ CDEV int stage_spheres(float4* exact, float4* filter, const SceneView& sc, int b
     const int padded = (cnt + 2 * kGroup - 1) / (2 * kGroup) * (2 * kGroup);
     for (int k = threadIdx.x; k < padded + kLdsSlack; k += kBlock) {
         exact[k] = (k < cnt) ? exact_image(sc.sph[base + k]) : exact_pad();
-#if !CASTER_STRICT
-        filter[k] = (k < cnt) ? sc.sph_filter[base + k] : filter_pad();
-#endif
+        filter[k] = (k < cnt) ? filter_image(sc.sph_filter[base + k], sc.sph_scale[base + k]) : filter_pad();
     }
     return padded;
 }
@@ -380,11 +370,7 @@ __global__ __launch_bounds__(kBlock, 4)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
     __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
-#if !CASTER_STRICT
     __shared__ float4 s_filter[kSphTile + 2 * kLdsSlack];
-#else
-    float4* s_filter = s_exact;
-#endif
     __shared__ float s_acc[kWaves][kTileW * kTileH * 3];
 
     const SceneView sc = view_of(a.scene);
