@@ -390,6 +390,18 @@ class CasterHip:
         )
         return dict(hit=hit, t=t, p=p3, n=n3, face=face, mat=mat)
 
+    def test_trace(self, ray6, strict=True):
+        ray6 = _f32(ray6, (-1, 6))
+        n = len(ray6)
+        hit, face, mat = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        t, p3, n3 = np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        _check(
+            self._lib.caster_hip_test_trace(self._ctx, C.c_uint32(STRICT if strict else 0), C.c_int(n), _ptr(ray6), _ptr(hit),
+                                            _ptr(t), _ptr(p3), _ptr(n3), _ptr(face), _ptr(mat)),
+            "caster_hip_test_trace",
+        )
+        return dict(hit=hit, t=t, p=p3, n=n3, face=face, mat=mat)
+
     def test_scatter(self, ray6, p3, n3, face, mat, seed, strict=True):
         ray6, p3, n3 = _f32(ray6, (-1, 6)), _f32(p3, (-1, 3)), _f32(n3, (-1, 3))
         face, mat = _i32(face), _i32(mat)

@@ -534,6 +534,35 @@ int caster_hip_test_hit_list(caster_hip_ctx* ctx, uint32_t flags, int n, const f
     return CASTER_HIP_OK;
 }
 
+int caster_hip_test_trace(caster_hip_ctx* ctx, uint32_t flags, int n, const float* ray6,
+                          int32_t* hit, float* t, float* p3, float* n3, int32_t* face, int32_t* mat)
+{
+    if (!ctx || !ray6 || !hit || !t || !p3 || !n3 || !face || !mat) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "no scene uploaded");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf dr, dhit, dtt, dp, dn, df, dm;
+    HIP_TRY(dr.put(ray6, sizeof(float) * 6 * n));
+    HIP_TRY(dhit.alloc(sizeof(int32_t) * n));
+    HIP_TRY(dtt.alloc(sizeof(float) * n));
+    HIP_TRY(dp.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(dn.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(df.alloc(sizeof(int32_t) * n));
+    HIP_TRY(dm.alloc(sizeof(int32_t) * n));
+    HIP_TRY(PICK(flags, launch_test_trace_)(ctx->scene, n, dr.as<float>(), dhit.as<int32_t>(), dtt.as<float>(),
+                                            dp.as<float>(), dn.as<float>(), df.as<int32_t>(), dm.as<int32_t>(),
+                                            ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dhit.get(hit, sizeof(int32_t) * n));
+    HIP_TRY(dtt.get(t, sizeof(float) * n));
+    HIP_TRY(dp.get(p3, sizeof(float) * 3 * n));
+    HIP_TRY(dn.get(n3, sizeof(float) * 3 * n));
+    HIP_TRY(df.get(face, sizeof(int32_t) * n));
+    HIP_TRY(dm.get(mat, sizeof(int32_t) * n));
+    return CASTER_HIP_OK;
+}
+
 int caster_hip_test_scatter(caster_hip_ctx* ctx, uint32_t flags, int n,
                             const float* ray6, const float* p3, const float* n3,
                             const int32_t* face, const int32_t* mat, uint32_t seed,

@@ -57,6 +57,9 @@ struct RenderArgs {
     hipError_t launch_test_hit_list_##SFX(const SceneDev& sc, int n, const float* ray6,           \
                                           int32_t* hit, float* t, float* p3, float* n3,           \
                                           int32_t* face, int32_t* mat, hipStream_t st);           \
+    hipError_t launch_test_trace_##SFX(const SceneDev& sc, int n, const float* ray6,              \
+                                       int32_t* hit, float* t, float* p3, float* n3,              \
+                                       int32_t* face, int32_t* mat, hipStream_t st);              \
     hipError_t launch_test_scatter_##SFX(const SceneDev& sc, int n, const float* ray6,            \
                                          const float* p3, const float* n3, const int32_t* face,   \
                                          const int32_t* mat, uint32_t seed, int32_t* ok,          \

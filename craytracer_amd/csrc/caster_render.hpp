@@ -167,6 +167,7 @@ CDEV float4 filter_image(const float4 h /* c'x, c'y, c'z, K = C - r*r (or -inf) 
 struct SphereLds {
     const float4* exact;
     const float4* filter;
+    int count;            // spheres in the tile, without the padding
 };
 
 struct PairRays {     // filter operands of both slots of a lane, packed
@@ -241,7 +242,8 @@ CDEV void process_sphere(const float4 f, const SphereLds& lds, int k, int index,
                          const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
     const f2 key = candidate_key(r, f);
-    if (is_candidate(key.x) || is_candidate(key.y)) {
+    // k < lds.count keeps a non-finite ray (NaN key) away from the tile's pad entries
+    if ((is_candidate(key.x) || is_candidate(key.y)) && k < lds.count) {
         const float4 e = lds.exact[k];
         if (is_candidate(key.x)) accept_one(e, index, sa, closestA, bestA);
         if (is_candidate(key.y)) accept_one(e, index, sb, closestB, bestB);
@@ -309,15 +311,10 @@ CDEV int stage_spheres(float4* exact, float4* filter, const SceneView& sc, int b
     return padded;
 }
 
-// After the sphere loop: merge the rects, build the hit record, shade, and
-// either continue the path or end it (adding its radiance to the tile).
-CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, float* tile_acc, unsigned int& rays)
+// After the sphere loop: merge the rects into the closest hit and build the
+// hit record (src/caster.c:216-223, 123-128, 153-161).  False on a miss.
+CDEV bool resolve_hit(const Slot& s, const Ray& r, float closest, int best_sph, const SceneView& sc, HitRec& rec)
 {
-    if (!s.alive) return;
-    rays++;
-    Ray r;
-    r.o = s.o;
-    r.d = s.d;
     int best_ord = (best_sph >= 0) ? sc.sph_meta[best_sph].x : -1;
     int best_rect = -1;
     for (int k = 0; k < sc.n_rect; ++k) {
@@ -327,17 +324,29 @@ CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, floa
             if (t < closest || ord > best_ord || best_ord < 0) { closest = t; best_ord = ord; best_rect = k; }
         }
     }
+    if (best_ord < 0) return false;
+    if (best_rect >= 0) {
+        finish_rect(rec, r, closest, sc.rect_a[best_rect], sc.rect_b[best_rect], sc.rect_meta[best_rect].y);
+    } else {
+        const float4 sp = sc.sph[best_sph];
+        finish_sphere(rec, r, closest, mk(sp.x, sp.y, sp.z), sp.w, sc.sph_meta[best_sph].y);
+    }
+    return true;
+}
 
+// One bounce of a slot's path: shade the hit and either continue the path or
+// end it (adding its radiance to the tile).
+CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, float* tile_acc, unsigned int& rays)
+{
+    if (!s.alive) return;
+    rays++;
+    Ray r;
+    r.o = s.o;
+    r.d = s.d;
     bool cont = false;
     V3 radiance = mk(0.0f, 0.0f, 0.0f);
-    if (best_ord >= 0) {
-        HitRec rec;
-        if (best_rect >= 0) {
-            finish_rect(rec, r, closest, sc.rect_a[best_rect], sc.rect_b[best_rect], sc.rect_meta[best_rect].y);
-        } else {
-            const float4 sp = sc.sph[best_sph];
-            finish_sphere(rec, r, closest, mk(sp.x, sp.y, sp.z), sp.w, sc.sph_meta[best_sph].y);
-        }
+    HitRec rec;
+    if (resolve_hit(s, r, closest, best_sph, sc, rec)) {
         Ray next;
         V3 atten, emit;
         cont = shade(sc, s.g, r, rec, next, atten, emit);
@@ -401,6 +410,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     SphereLds lds;
     lds.exact = s_exact;
     lds.filter = s_filter;
+    lds.count = sc.n_sph;
     const float3 ref = make_float3(a.scene.ref[0], a.scene.ref[1], a.scene.ref[2]);
     __syncthreads();
 
@@ -443,6 +453,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
                 const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
                 if (base) __syncthreads();           // everyone is done with the previous tile
                 const int padded = stage_spheres(s_exact, s_filter, sc, base, cnt);
+                lds.count = cnt;
                 __syncthreads();
                 isect_tile(lds, padded, base, pr, sa, sb, closestA, closestB, bestA, bestB);
             }
@@ -462,6 +473,74 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     unsigned int wrays = rays;
     for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
     if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
+}
+
+// hit_list_hit_all for an array of rays through the render kernel's own
+// machinery: LDS staging, candidate filter, packed two-slot sphere loop, rect
+// merge.  Lane t of a block traces rays 2t and 2t+1 of the block's 512.
+__global__ __launch_bounds__(kBlock, 4)
+void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* hit, float* t, float* p3,
+                                float* n3, int32_t* face, int32_t* mat)
+{
+    __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
+    __shared__ float4 s_filter[kSphTile + 2 * kLdsSlack];
+    const SceneView sc = view_of(sd);
+    SphereLds lds;
+    lds.exact = s_exact;
+    lds.filter = s_filter;
+    lds.count = 0;
+    const float3 ref = make_float3(sd.ref[0], sd.ref[1], sd.ref[2]);
+    const int i0 = (blockIdx.x * kBlock + threadIdx.x) * 2;
+    Slot sl[2];
+    Ray rr[2];
+    float len[2];
+    for (int k = 0; k < 2; ++k) {
+        park(sl[k]);
+        len[k] = 1.0f;
+        rr[k].o = mk(0, 0, 0); rr[k].d = mk(0, 0, 1);
+        if (i0 + k < n) {
+            const float* q = ray6 + 6 * (size_t)(i0 + k);
+            rr[k].o = mk(q[0], q[1], q[2]);
+            rr[k].d = mk(q[3], q[4], q[5]);
+            set_ray(sl[k], rr[k]);
+            sl[k].alive = true;
+#if !CASTER_STRICT
+            len[k] = sl[k].tmin / kTMin;
+#endif
+        }
+    }
+    float closest[2] = {sl[0].tmax, sl[1].tmax};
+    int best[2] = {-1, -1};
+    const PairRays pr = pack_rays(sl[0], sl[1], ref);
+    for (int base = 0; base < sc.n_sph; base += kSphTile) {
+        const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
+        __syncthreads();
+        const int padded = stage_spheres(s_exact, s_filter, sc, base, cnt);
+        lds.count = cnt;
+        __syncthreads();
+        isect_tile(lds, padded, base, pr, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (i0 + k >= n) continue;
+        const int i = i0 + k;
+        HitRec rec;
+        rec.t = 0; rec.f = 0; rec.p = mk(0, 0, 0); rec.n = mk(0, 0, 0); rec.m = -1;
+        Ray r;
+        r.o = sl[k].o; r.d = sl[k].d;
+        const bool ok = resolve_hit(sl[k], r, closest[k], best[k], sc, rec);
+        hit[i] = ok; t[i] = ok ? rec.t / len[k] : 0.0f; face[i] = ok ? rec.f : 0; mat[i] = ok ? rec.m : -1;
+        p3[3 * i] = rec.p.x; p3[3 * i + 1] = rec.p.y; p3[3 * i + 2] = rec.p.z;
+        n3[3 * i] = rec.n.x; n3[3 * i + 1] = rec.n.y; n3[3 * i + 2] = rec.n.z;
+    }
+}
+
+hipError_t CASTER_NAME(launch_test_trace_)(const SceneDev& sc, int n, const float* ray6, int32_t* hit, float* t,
+                                           float* p3, float* n3, int32_t* face, int32_t* mat, hipStream_t st)
+{
+    const int per_block = kBlock * 2;
+    hipLaunchKernelGGL(CASTER_NAME(k_test_trace_), dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), 0,
+                       st, sc, n, ray6, hit, t, p3, n3, face, mat);
+    return hipGetLastError();
 }
 
 hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a, hipStream_t st)

@@ -154,6 +154,12 @@ int caster_hip_test_hit_xy_rect(caster_hip_ctx* ctx, uint32_t flags, int n,
 int caster_hip_test_hit_list(caster_hip_ctx* ctx, uint32_t flags, int n, const float* ray6,
                              int32_t* hit, float* t, float* p3, float* n3, int32_t* face,
                              int32_t* mat);
+/* The same closest-hit query through the render kernel's own sphere loop (LDS staging,
+ * candidate filter, two packed ray slots per lane, rect merge), so that the production
+ * intersection path can be checked ray by ray against hit_list_hit_all. */
+int caster_hip_test_trace(caster_hip_ctx* ctx, uint32_t flags, int n, const float* ray6,
+                          int32_t* hit, float* t, float* p3, float* n3, int32_t* face,
+                          int32_t* mat);
 /* ray_scatter_{lambertian,metal,dielectric} by mat[k]'s type (src/material.c:3-43);
  * item k draws from the stream keyed (seed, k, 0).  draws = random_f32 calls made. */
 int caster_hip_test_scatter(caster_hip_ctx* ctx, uint32_t flags, int n,

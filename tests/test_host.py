@@ -1,0 +1,138 @@
+"""Host-side logic that needs no GPU: the C ABI library loads and exports every entry point of
+include/caster_hip.h, compute entry points fail loudly without a device, the C host's scenes,
+camera, flattening and BMP writer behave as the reference's host code, and the product never
+touches the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_entry_points():
+    header = open(os.path.join(ROOT, "include", "caster_hip.h")).read()
+    return sorted(set(re.findall(r"\b(caster_hip_[a-z_0-9]+)\s*\(", header)))
+
+
+def test_c_abi_exports_every_declared_symbol(ca):
+    lib = ca.load_caster_lib()
+    names = _declared_entry_points()
+    assert len(names) >= 20
+    for name in names:
+        assert getattr(lib, name) is not None, name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", ca.lib_paths()["caster"]], text=True)
+    exported = set(re.findall(r" T (caster_hip_[a-z_0-9]+)", out))
+    assert set(names) <= exported
+    # plain C ABI: nothing but caster_hip_* is exported with C linkage from the API unit
+    assert not [s for s in exported if not s.startswith("caster_hip_")]
+
+
+def test_no_device_is_a_loud_error(ca):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device path cannot be exercised")
+    with pytest.raises(ca.CasterHipError) as e:
+        ca.CasterHip(0)
+    assert "no CPU fallback" in str(e.value) or "HIP" in str(e.value)
+    lib = ca.load_caster_lib()
+    n = ctypes.c_int(-1)
+    rc = lib.caster_hip_device_count(ctypes.byref(n))
+    assert rc != 0 or n.value == 0
+    assert lib.caster_hip_render(None, None, 1, 1, 0, 1, 1, 0, 0, None) != 0       # NULL ctx: argument error
+    assert b"NULL" in lib.caster_hip_last_error()
+
+
+def test_product_never_references_the_oracle():
+    bad = []
+    for base in ("craytracer_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".c", ".h", ".hpp", ".hip", ".cpp", "Makefile")):
+                    text = open(os.path.join(dirpath, f), errors="replace").read()
+                    if re.search(r"oracle|orc_", text):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_scene_0_matches_reference_setup(ca):
+    """src/main.c:14-55: ground checker sphere, glass sphere, third sphere, emissive xy rect, in that order."""
+    fs = ca.scene_0()
+    assert fs.objects["type"].tolist() == [0, 0, 0, 1]
+    assert np.allclose(fs.objects["g"][0, :4], [0, -1000, 0, 1000])
+    assert np.allclose(fs.objects["g"][1, :4], [4, 1, 0, 1])
+    assert np.allclose(fs.objects["g"][2, :4], [4, 1, 3, 1])
+    assert np.allclose(fs.objects["g"][3, :5], [4, 2, -2, 2, 2])
+    m = fs.materials
+    assert m["type"].tolist() == [0, 2, 0, 3] and m["tex_type"].tolist() == [1, 0, 0, 0]
+    assert np.allclose(m["color0"][0], 1) and np.allclose(m["color1"][0], 0)
+    assert m["n_refract"][1] == np.float32(1.5)
+    assert np.allclose(m["color0"][3], 2)
+    tex = ca.scene_0(textured=True)
+    assert tex.materials["tex_type"][2] == 2 and tex.materials["image"][2] == 0 and tex.images[0].shape == (128, 256, 3)
+
+
+def test_rtiow_and_stress_scenes(ca):
+    a, b = ca.scene_rtiow(1), ca.scene_rtiow(1)
+    assert np.array_equal(a.objects, b.objects) and np.array_equal(a.materials, b.materials)      # deterministic
+    c = ca.scene_rtiow(2)
+    assert not np.array_equal(a.objects["g"], c.objects["g"][: len(a.objects)]) if len(a.objects) == len(c.objects) else True
+    assert 470 <= len(a.objects) <= 489 and (a.objects["type"] == 0).all()
+    assert np.allclose(a.objects["g"][0, :4], [0, -1000, 0, 1000])
+    assert np.allclose(a.objects["g"][-1, :4], [0, 0, 0, 100000]) and a.materials["type"][a.objects["material"][-1]] == 3
+    # the three big spheres: glass, diffuse (0.4,0.2,0.1), metal (0.7,0.6,0.5) fuzz 0 -- src/main.c:24-26
+    big = a.objects[-4:-1]
+    assert np.allclose(big["g"][:, 3], 1.0)
+    mats = a.materials[big["material"]]
+    assert mats["type"].tolist() == [2, 0, 1]
+    assert np.allclose(mats["color0"][1], [0.4, 0.2, 0.1]) and np.allclose(mats["color0"][2], [0.7, 0.6, 0.5])
+    small = a.objects[1:-4]
+    assert np.allclose(small["g"][:, 3], 0.2) and np.allclose(small["g"][:, 1], 0.2)
+    kinds = np.bincount(a.materials["type"][small["material"]], minlength=3) / len(small)
+    assert 0.7 < kinds[0] < 0.9 and 0.08 < kinds[1] < 0.22 and 0.01 < kinds[2] < 0.1
+    s = ca.scene_stress(1000, 2)
+    assert len(s.objects) == 1002 and np.allclose(s.objects["g"][-1, 3], 100000)
+    r = s.objects["g"][1:-1, 3]
+    assert r.min() >= 0.1 and r.max() <= 0.5
+
+
+def test_host_camera_equals_oracle_camera(ca, orc):
+    for aspect in (16 / 9, 4 / 3, 1.0):
+        assert np.array_equal(ca.default_camera(aspect), orc.default_camera(aspect))
+    a = ca.calculate_cam_info((1, 2, 3), (0, 0.5, -1), (0, 1, 0), 40.0, 1.5, 0.3, 4.0)
+    b = orc.calculate_cam_info((1, 2, 3), (0, 0.5, -1), (0, 1, 0), 40.0, 1.5, 0.3, 4.0)
+    assert np.array_equal(a, b)
+
+
+def test_host_bmp_writer_bytes(ca, orc):
+    rng = np.random.default_rng(0)
+    for w, h in ((3, 2), (5, 4), (16, 9), (7, 1)):
+        rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        assert ca.bmp_encode(rgba) == orc.bmp_bytes(rgba)
+
+
+def test_cli_rejects_bad_arguments(ca):
+    exe = os.path.join(os.path.dirname(ca.lib_paths()["host"]), "craytracer")
+    assert os.path.exists(exe)
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 2 and "usage" in p.stderr
+    p = subprocess.run([exe, "90", "1", "5", "1", "--scene", "nope"], capture_output=True, text=True)
+    assert p.returncode != 0
+
+
+def test_sample_partition():
+    from craytracer_amd.frame import sample_partition
+
+    for spp in (0, 1, 7, 500, 2000):
+        for world in (1, 2, 3, 4, 8):
+            parts = [sample_partition(spp, world, r) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == spp
+            for (b0, c0), (b1, _) in zip(parts, parts[1:]):
+                assert b0 + c0 == b1
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+    with pytest.raises(ValueError):
+        sample_partition(10, 2, 2)
