@@ -242,8 +242,8 @@ CDEV void process_sphere(const float4 f, const SphereLds& lds, int k, int index,
                          const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
     const f2 key = candidate_key(r, f);
-    // k < lds.count keeps a non-finite ray (NaN key) away from the tile's pad entries
-    if ((is_candidate(key.x) || is_candidate(key.y)) && k < lds.count) {
+    // one branch for the pair of slots; `|` instead of `||` keeps it a single test
+    if (is_candidate(key.x) | is_candidate(key.y)) {
         const float4 e = lds.exact[k];
         if (is_candidate(key.x)) accept_one(e, index, sa, closestA, bestA);
         if (is_candidate(key.y)) accept_one(e, index, sb, closestB, bestB);
@@ -315,6 +315,9 @@ CDEV int stage_spheres(float4* exact, float4* filter, const SceneView& sc, int b
 // hit record (src/caster.c:216-223, 123-128, 153-161).  False on a miss.
 CDEV bool resolve_hit(const Slot& s, const Ray& r, float closest, int best_sph, const SceneView& sc, HitRec& rec)
 {
+    // A non-finite ray makes every test "accept" (NaN passes the range checks, src/caster.c:107,114),
+    // the pad entries of the last LDS tile included; the reference would report its last sphere.
+    if (best_sph >= sc.n_sph) best_sph = sc.n_sph - 1;
     int best_ord = (best_sph >= 0) ? sc.sph_meta[best_sph].x : -1;
     int best_rect = -1;
     for (int k = 0; k < sc.n_rect; ++k) {
