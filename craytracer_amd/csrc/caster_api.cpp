@@ -46,7 +46,8 @@ struct caster_hip_ctx {
     // scratch
     float4* slabs = nullptr;
     size_t slab_bytes = 0;
-    unsigned long long* rays_dev = nullptr;
+    unsigned long long* rays_dev = nullptr;   // [0] rays, [1] low word: work-unit queue head
+    int resident_blocks = 1024;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool render_pending = false;
     int chunk = 0;  // samples per work unit; 0 = automatic
@@ -149,10 +150,16 @@ int caster_hip_create(int device, caster_hip_ctx** out)
     caster_hip_ctx* ctx = new (std::nothrow) caster_hip_ctx();
     if (!ctx) return fail(CASTER_HIP_ERR_ARG, "out of host memory");
     ctx->device = device;
+    {
+        // persistent grid: 4 blocks of 4 waves per CU (the kernel is built for 4 waves per SIMD)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->resident_blocks = prop.multiProcessorCount * 4;
+    }
     const char* env_chunk = getenv("CASTER_HIP_CHUNK");
     if (env_chunk) ctx->chunk = atoi(env_chunk);
-    if (hipMalloc(reinterpret_cast<void**>(&ctx->rays_dev), sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->rays_dev, 0, sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->rays_dev), 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->rays_dev, 0, 2 * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         caster_hip_destroy(ctx);
         return fail(CASTER_HIP_ERR_DEVICE, "context allocation on device %d failed", device);
@@ -357,7 +364,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     if (sample_begin < 0 || sample_count < 0) return fail(CASTER_HIP_ERR_ARG, "negative sample range");
     if ((flags & ~(uint32_t)CASTER_HIP_STRICT) != 0) return fail(CASTER_HIP_ERR_ARG, "unknown flag bits 0x%x", flags);
     DeviceGuard guard(ctx->device);
-    HIP_TRY(hipMemsetAsync(ctx->rays_dev, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->rays_dev, 0, 2 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     ctx->render_pending = true;
     if (sample_count == 0) {
@@ -365,7 +372,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
         return CASTER_HIP_OK;
     }
 
-    int chunk = ctx->chunk > 0 ? ctx->chunk : 128;
+    int chunk = ctx->chunk > 0 ? ctx->chunk : 32;
     if (chunk > sample_count) chunk = sample_count;
     const int n_chunks = (sample_count + chunk - 1) / chunk;
     const size_t n_pixels = (size_t)width * height;
@@ -389,8 +396,11 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     a.seed = seed;
     a.slabs = ctx->slabs;
     a.rays = ctx->rays_dev;
-    if (flags & CASTER_HIP_STRICT) HIP_TRY(caster::launch_render_strict(a, ctx->stream));
-    else HIP_TRY(caster::launch_render_fast(a, ctx->stream));
+    a.queue = reinterpret_cast<unsigned int*>(ctx->rays_dev + 1);
+    a.n_units = 0;
+    a.lds_spheres = 0;
+    if (flags & CASTER_HIP_STRICT) HIP_TRY(caster::launch_render_strict(a, ctx->resident_blocks, ctx->stream));
+    else HIP_TRY(caster::launch_render_fast(a, ctx->resident_blocks, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(caster::launch_combine(ctx->slabs, n_chunks, (int)n_pixels, reinterpret_cast<float4*>(accum_dev),
                                    ctx->stream));

@@ -44,10 +44,13 @@ struct RenderArgs {
     uint32_t seed;
     float4* slabs;           // n_chunks * width * height partial sums
     unsigned long long* rays;
+    unsigned int* queue;     // work-unit queue head, zero at launch
+    int n_units;             // filled in by the launcher
+    int lds_spheres;         // float4 slots per sphere image in LDS (filled in by the launcher)
 };
 
 #define CASTER_DECLARE_LAUNCHERS(SFX)                                                             \
-    hipError_t launch_render_##SFX(const RenderArgs& a, hipStream_t st);                          \
+    hipError_t launch_render_##SFX(const RenderArgs& a, int resident_blocks, hipStream_t st);                          \
     hipError_t launch_test_hit_sphere_##SFX(int n, const float* sph4, const float* ray6,          \
                                             const float* tr2, int32_t* hit, float* t, float* p3,  \
                                             float* n3, int32_t* face, hipStream_t st);            \

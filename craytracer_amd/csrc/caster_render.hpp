@@ -3,23 +3,29 @@
 // (src/dispatcher.c:12-30) by an iterative loop over a pool of paths.
 //
 // Work decomposition
-//   * a work unit is an 8x8 pixel tile times a chunk of the sample range; one
-//     wave owns one unit, a 256-thread block holds four waves that share one
-//     copy of the sphere list in LDS;
+//   * a work unit is an 8x8 pixel tile times a chunk of the sample range.  The
+//     grid is persistent: every wave pulls units from a queue (one atomic add
+//     per unit) until it is empty; a 256-thread block holds four waves that
+//     share one copy of the sphere list in LDS;
 //   * every lane carries TWO path slots, so a wave traces 128 rays per loop
 //     trip and the sphere test runs on packed FP32 (v_pk_*_f32: slot A in the
 //     low half, slot B in the high half), one LDS broadcast read per sphere;
-//   * when a path ends, its radiance is added to the tile's accumulator in LDS
+//   * when a path ends, its radiance is added to the unit's accumulator in LDS
 //     and the slot takes the next (pixel, sample) of the unit's pool: the
 //     finished slots are found with a ballot and numbered with mbcnt, so the
-//     wave stays full until the pool is empty;
-//   * the unit's sums go to a slab private to its chunk; a later kernel adds
-//     the slabs in chunk order (no float atomics in global memory, renders are
-//     bit-reproducible).
+//     wave stays full.  When the pool runs dry the wave starts on its next
+//     unit while the last paths of the previous one are still in flight (two
+//     accumulator sets per wave); it never idles waiting for long paths;
+//   * the accumulators are 64-bit fixed point (2^-32 units): integer adds
+//     commute, so the sums do not depend on the order in which paths end and a
+//     render is bit-reproducible although the unit-to-wave assignment is not;
+//   * a finished unit's sums go to a slab private to its chunk; a later kernel
+//     adds the slabs in chunk order (no float atomics in global memory).
 //
 // Every ray is tested against every sphere (src/caster.c:204 has no early
-// out): the loop computes the discriminant for both slots branch-free and
-// enters the root/closest-hit code only when some lane has a candidate.
+// out): the loop evaluates a conservative candidate test for both slots
+// branch-free and enters the root/closest-hit code only when some lane has a
+// candidate.
 #pragma once
 
 #include "caster_device.hpp"
@@ -43,7 +49,7 @@ struct Slot {
     float tmax;     // strict: 16777215 ; fast: 16777215 * |d|
     V3 thr;         // product of the attenuations so far
     Rng g;
-    int q;          // pixel of the tile this path belongs to (0..63)
+    int q;          // pixel of the tile this path belongs to (bits 0-5), accumulator set (bit 6)
     int depth;      // rays this path may still shoot
     bool alive;
 };
@@ -86,41 +92,99 @@ struct TileGeom {
     int tw, th;     // valid pixels (partial tiles at the right / top edge)
 };
 
-// Camera ray for pool entry m of the unit: src/dispatcher.c:21-24.
-CDEV void start_pool_path(Slot& s, int m, const TileGeom& tg, int s0, const RenderArgs& a, const Cam& cam)
+// A work unit as a wave sees it (all fields wave-uniform).
+struct Unit {
+    int chunk;      // index of the sample chunk, -1 = no unit
+    TileGeom tg;
+    int s0, cs;     // first sample and number of samples of the chunk
+    int next, total;// pool cursor / pool size (pixels x samples)
+};
+
+constexpr int kAccStride = kTileW * kTileH * 3;     // one accumulator set: 64 pixels x RGB
+typedef unsigned long long acc_t;                   // fixed point, 32 fractional bits
+constexpr double kAccScale = 4294967296.0;
+
+// Pulls the next unit off the queue.  Units are numbered chunk-major.
+CDEV Unit fetch_unit(const RenderArgs& a, int tiles_x, int n_tiles, int lane)
 {
-    const int nvalid = tg.tw * tg.th;
+    unsigned int u = 0;
+    if (lane == 0) u = atomicAdd(a.queue, 1u);
+    u = (unsigned int)__builtin_amdgcn_readfirstlane((int)u);
+    Unit un;
+    un.chunk = -1; un.s0 = 0; un.cs = 0; un.next = 0; un.total = 0;
+    un.tg.x0 = un.tg.y0 = 0; un.tg.tw = un.tg.th = 0;
+    if (u >= (unsigned int)a.n_units) return un;
+    const int chunk = (int)(u / (unsigned int)n_tiles);
+    const int tile = (int)u - chunk * n_tiles;
+    un.chunk = chunk;
+    un.tg.x0 = (tile % tiles_x) * kTileW;
+    un.tg.y0 = (tile / tiles_x) * kTileH;
+    un.tg.tw = (a.width - un.tg.x0 < kTileW) ? a.width - un.tg.x0 : kTileW;
+    un.tg.th = (a.height - un.tg.y0 < kTileH) ? a.height - un.tg.y0 : kTileH;
+    un.s0 = a.s_begin + chunk * a.chunk;
+    const int s_end = a.s_begin + a.s_count;
+    un.cs = (un.s0 + a.chunk < s_end) ? a.chunk : s_end - un.s0;
+    un.total = (a.max_depth > 0) ? un.tg.tw * un.tg.th * un.cs : 0;
+    return un;
+}
+
+// Camera ray for pool entry m of the unit: src/dispatcher.c:21-24.
+CDEV void start_pool_path(Slot& s, int m, const Unit& un, int set, const RenderArgs& a, const Cam& cam)
+{
+    const int nvalid = un.tg.tw * un.tg.th;
     int smp, qx, qy;
     if (nvalid == 64) {
         smp = m >> 6; qx = m & 7; qy = (m >> 3) & 7;
     } else {
         smp = m / nvalid;
         const int rem = m - smp * nvalid;
-        qy = rem / tg.tw;
-        qx = rem - qy * tg.tw;
+        qy = rem / un.tg.tw;
+        qx = rem - qy * un.tg.tw;
     }
-    const int i = tg.x0 + qx, j = tg.y0 + qy;
-    rng_seed(s.g, a.seed, (uint32_t)(j * a.width + i), (uint32_t)(s0 + smp));
+    const int i = un.tg.x0 + qx, j = un.tg.y0 + qy;
+    rng_seed(s.g, a.seed, (uint32_t)(j * a.width + i), (uint32_t)(un.s0 + smp));
     const float u = ((float)i + random_f32(s.g)) / (float)(a.width - 1);
     const float v = ((float)j + random_f32(s.g)) / (float)(a.height - 1);
     const Ray r = ray_from_cam(cam, s.g, u, v);
     set_ray(s, r);
     s.thr = mk(1.0f, 1.0f, 1.0f);
-    s.q = qy * kTileW + qx;
+    s.q = (set << 6) | (qy * kTileW + qx);
     s.depth = a.max_depth;
     s.alive = true;
 }
 
-// Slots without a path take the next entries of the pool, in lane order.
-CDEV void refill(Slot& s, int& next, int total, const TileGeom& tg, int s0, const RenderArgs& a, const Cam& cam)
+// Slots without a path take the next entries of the unit's pool, in lane order.
+CDEV void refill(Slot& s, Unit& un, int set, const RenderArgs& a, const Cam& cam)
 {
-    if (next >= total) return;                       // wave-uniform
+    if (un.chunk < 0 || un.next >= un.total) return;             // wave-uniform
     const unsigned long long want = __ballot(!s.alive);
     if (want == 0ull) return;
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
-    const int m = next + rank;
-    if (!s.alive && m < total) start_pool_path(s, m, tg, s0, a, cam);
-    next += __popcll(want);
+    const int m = un.next + rank;
+    if (!s.alive && m < un.total) start_pool_path(s, m, un, set, a, cam);
+    un.next += __popcll(want);
+}
+
+// Writes a finished unit's sums to its chunk's slab and clears the accumulator set.
+CDEV void flush_unit(const Unit& un, acc_t* acc_set, const RenderArgs& a, int lane)
+{
+    const int qx = lane & 7, qy = lane >> 3;
+    const float r = (float)((double)acc_set[lane * 3 + 0] * (1.0 / kAccScale));
+    const float g = (float)((double)acc_set[lane * 3 + 1] * (1.0 / kAccScale));
+    const float b = (float)((double)acc_set[lane * 3 + 2] * (1.0 / kAccScale));
+    if (qx < un.tg.tw && qy < un.tg.th) {
+        const size_t px = (size_t)(un.tg.y0 + qy) * a.width + (un.tg.x0 + qx);
+        a.slabs[(size_t)un.chunk * a.width * a.height + px] = make_float4(r, g, b, (float)un.cs);
+    }
+    acc_set[lane * 3 + 0] = 0; acc_set[lane * 3 + 1] = 0; acc_set[lane * 3 + 2] = 0;
+    __builtin_amdgcn_wave_barrier();
+}
+
+CDEV acc_t to_fixed(float x)
+{
+    // radiance is a product of colours and an emission: finite and >= 0 for any sane scene
+    const double d = (double)fminf(fmaxf(x, 0.0f), 1.0e9f) * kAccScale;
+    return (acc_t)d;
 }
 
 // ---- sphere loop ---------------------------------------------------------
@@ -339,7 +403,7 @@ CDEV bool resolve_hit(const Slot& s, const Ray& r, float closest, int best_sph, 
 
 // One bounce of a slot's path: shade the hit and either continue the path or
 // end it (adding its radiance to the tile).
-CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, float* tile_acc, unsigned int& rays)
+CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, acc_t* wave_acc, unsigned int& rays)
 {
     if (!s.alive) return;
     rays++;
@@ -363,9 +427,10 @@ CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, floa
         }
     }
     if (!cont) {
-        atomicAdd(&tile_acc[s.q * 3 + 0], radiance.x);
-        atomicAdd(&tile_acc[s.q * 3 + 1], radiance.y);
-        atomicAdd(&tile_acc[s.q * 3 + 2], radiance.z);
+        // s.q = set * 64 + pixel: the two sets are contiguous
+        if (radiance.x != 0.0f) atomicAdd(&wave_acc[s.q * 3 + 0], to_fixed(radiance.x));
+        if (radiance.y != 0.0f) atomicAdd(&wave_acc[s.q * 3 + 1], to_fixed(radiance.y));
+        if (radiance.z != 0.0f) atomicAdd(&wave_acc[s.q * 3 + 2], to_fixed(radiance.z));
         park(s);
     }
 }
@@ -381,9 +446,11 @@ template <bool TILED>
 __global__ __launch_bounds__(kBlock, 4)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
-    __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
-    __shared__ float4 s_filter[kSphTile + 2 * kLdsSlack];
-    __shared__ float s_acc[kWaves][kTileW * kTileH * 3];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    // layout: accumulators [kWaves][2][kAccStride] (acc_t), then the two sphere images
+    acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
+    float4* s_exact = reinterpret_cast<float4*>(s_dyn + sizeof(acc_t) * kWaves * 2 * kAccStride);
+    float4* s_filter = s_exact + a.lds_spheres;
 
     const SceneView sc = view_of(a.scene);
     const Cam cam = cam_of(a.cam);
@@ -392,22 +459,9 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     const int tiles_x = (a.width + kTileW - 1) / kTileW;
     const int tiles_y = (a.height + kTileH - 1) / kTileH;
     const int n_tiles = tiles_x * tiles_y;
-    const int unit = blockIdx.x * kWaves + wave;
-    const int chunk = unit / n_tiles;
-    const int tile = unit - chunk * n_tiles;
-    const bool has_unit = chunk < a.n_chunks;
-    TileGeom tg;
-    tg.x0 = (tile % tiles_x) * kTileW;
-    tg.y0 = (tile / tiles_x) * kTileH;
-    tg.tw = (a.width - tg.x0 < kTileW) ? a.width - tg.x0 : kTileW;
-    tg.th = (a.height - tg.y0 < kTileH) ? a.height - tg.y0 : kTileH;
-    const int s0 = a.s_begin + chunk * a.chunk;
-    const int s_end = a.s_begin + a.s_count;
-    const int cs = has_unit ? ((s0 + a.chunk < s_end) ? a.chunk : s_end - s0) : 0;
-    const int total = (a.max_depth > 0) ? tg.tw * tg.th * cs : 0;
 
-    float* tile_acc = s_acc[wave];
-    for (int k = lane; k < kTileW * kTileH * 3; k += 64) tile_acc[k] = 0.0f;
+    acc_t* wave_acc = s_acc + wave * 2 * kAccStride;
+    for (int k = lane; k < 2 * kAccStride; k += 64) wave_acc[k] = 0;
     int n_lds = 0;
     if (!TILED) n_lds = stage_spheres(s_exact, s_filter, sc, 0, sc.n_sph);
     SphereLds lds;
@@ -424,27 +478,69 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     sa.q = sb.q = 0; sa.depth = sb.depth = 0;
     park(sa);
     park(sb);
-    int next = 0;
     unsigned int rays = 0;
     float closestA = kTMax, closestB = kTMax;
     int bestA = -1, bestB = -1;
 
+    Unit cur, prev;                 // cur feeds the slots; prev only waits for its last paths
+    cur.chunk = prev.chunk = -1;
+    cur.next = cur.total = prev.next = prev.total = 0;
+    cur.cs = prev.cs = cur.s0 = prev.s0 = 0;
+    cur.tg.x0 = cur.tg.y0 = cur.tg.tw = cur.tg.th = 0;
+    prev.tg = cur.tg;
+    int set = 0;                    // accumulator set of cur; prev owns the other one
+    bool queue_empty = false;
+
     for (;;) {
         // One copy of the per-slot code serves both slots (the slots trade places
         // after each turn), so a path computes the same values in either slot.
-        // On the first trip both slots are parked: bounce() does nothing and
-        // refill() starts the first 128 paths.
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {
-            bounce(sa, closestA, bestA, sc, tile_acc, rays);
-            refill(sa, next, total, tg, s0, a, cam);
+            bounce(sa, closestA, bestA, sc, wave_acc, rays);
             swap_slots(sa, sb);
             float tf = closestA; closestA = closestB; closestB = tf;
             int ti = bestA; bestA = bestB; bestB = ti;
         }
+
+        // retire the previous unit once its last path has ended
+        if (prev.chunk >= 0) {
+            const int pset = set ^ 1;
+            const bool mine = (sa.alive && (sa.q >> 6) == pset) || (sb.alive && (sb.q >> 6) == pset);
+            if (!__any(mine ? 1 : 0)) {
+                flush_unit(prev, wave_acc + pset * kAccStride, a, lane);
+                prev.chunk = -1;
+            }
+        }
+        // the current unit's pool is empty: it becomes the one that waits, the wave moves on
+        if (cur.chunk >= 0 && cur.next >= cur.total && prev.chunk < 0) {
+            prev = cur;
+            cur.chunk = -1;
+            set ^= 1;
+        }
+        if (cur.chunk < 0 && !queue_empty) {
+            cur = fetch_unit(a, tiles_x, n_tiles, lane);
+            queue_empty = cur.chunk < 0;
+        }
+
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {
+            refill(sa, cur, set, a, cam);
+            swap_slots(sa, sb);
+        }
+
         const int live = (sa.alive || sb.alive) ? 1 : 0;
-        const bool any_live = TILED ? (__syncthreads_or(live) != 0) : (__any(live) != 0);
-        if (!any_live) break;
+        const bool done = queue_empty && cur.chunk < 0 && prev.chunk < 0;
+        if (TILED) {
+            // the tile loop below has block-wide barriers: all four waves leave together
+            if (__syncthreads_or((live || !done) ? 1 : 0) == 0) break;
+        } else {
+            if (__any(live) == 0) {
+                if (done) break;
+                closestA = closestB = kTMax;
+                bestA = bestB = -1;
+                continue;           // nothing to trace; units still have to be retired or fetched
+            }
+        }
 
         closestA = sa.tmax; closestB = sb.tmax;
         bestA = -1; bestB = -1;
@@ -463,19 +559,35 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         }
     }
 
-    if (has_unit) {
-        // lane l writes pixel l of the tile
-        const int qx = lane & 7, qy = lane >> 3;
-        if (qx < tg.tw && qy < tg.th) {
-            const size_t px = (size_t)(tg.y0 + qy) * a.width + (tg.x0 + qx);
-            a.slabs[(size_t)chunk * a.width * a.height + px] =
-                make_float4(tile_acc[lane * 3 + 0], tile_acc[lane * 3 + 1], tile_acc[lane * 3 + 2], (float)cs);
-        }
-    }
-
     unsigned int wrays = rays;
     for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
     if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
+}
+
+// LDS bytes of a render launch: accumulators + both sphere images of one tile.
+static inline int lds_sphere_slots(int n_sph)
+{
+    const int tile = n_sph < kSphTile ? n_sph : kSphTile;
+    return (tile + 2 * kGroup - 1) / (2 * kGroup) * (2 * kGroup) + kLdsSlack;
+}
+
+hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_blocks, hipStream_t st)
+{
+    RenderArgs a = a_in;
+    const int tiles_x = (a.width + kTileW - 1) / kTileW;
+    const int tiles_y = (a.height + kTileH - 1) / kTileH;
+    const long long units = (long long)tiles_x * tiles_y * a.n_chunks;
+    if (units <= 0 || units > 0x7fffffffLL) return hipErrorInvalidValue;
+    a.n_units = (int)units;
+    a.lds_spheres = lds_sphere_slots(a.scene.n_sph);
+    const size_t lds_bytes = sizeof(acc_t) * kWaves * 2 * kAccStride + 2 * sizeof(float4) * (size_t)a.lds_spheres;
+    long long blocks = (units + kWaves - 1) / kWaves;
+    if (blocks > resident_blocks) blocks = resident_blocks;      // persistent: the waves loop over the queue
+    if (a.scene.n_sph > kSphTile)
+        hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<true>, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, st, a);
+    else
+        hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<false>, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, st, a);
+    return hipGetLastError();
 }
 
 // hit_list_hit_all for an array of rays through the render kernel's own
