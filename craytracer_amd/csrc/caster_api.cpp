@@ -1,5 +1,5 @@
 // C ABI of libcaster_hip (see include/caster_hip.h).  Host side only: argument
-// checks, scene flattening into device arrays, scratch slabs, kernel launches.
+// checks, scene flattening into device arrays, the fixed-point frame buffer, kernel launches.
 #include "caster_hip.h"
 #include "caster_launch.h"
 
@@ -44,8 +44,8 @@ struct caster_hip_ctx {
     caster::SceneDev scene{};
     std::vector<void*> scene_allocs;
     // scratch
-    float4* slabs = nullptr;
-    size_t slab_bytes = 0;
+    unsigned long long* fixed = nullptr;      // per-pixel fixed-point sums of the call in flight
+    size_t fixed_bytes = 0;
     unsigned long long* rays_dev = nullptr;   // [0] rays, [1] low word: work-unit queue head
     int resident_blocks = 1024;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -174,7 +174,7 @@ int caster_hip_destroy(caster_hip_ctx* ctx)
     DeviceGuard guard(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
-    if (ctx->slabs) (void)hipFree(ctx->slabs);
+    if (ctx->fixed) (void)hipFree(ctx->fixed);
     if (ctx->rays_dev) (void)hipFree(ctx->rays_dev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -376,15 +376,16 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     if (chunk > sample_count) chunk = sample_count;
     const int n_chunks = (sample_count + chunk - 1) / chunk;
     const size_t n_pixels = (size_t)width * height;
-    const size_t need = n_pixels * sizeof(float4) * (size_t)n_chunks;
-    if (need > ctx->slab_bytes) {
+    const size_t need = n_pixels * 4 * sizeof(unsigned long long);
+    if (need > ctx->fixed_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ctx->slabs) HIP_TRY(hipFree(ctx->slabs));
-        ctx->slabs = nullptr;
-        ctx->slab_bytes = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->slabs), need));
-        ctx->slab_bytes = need;
+        if (ctx->fixed) HIP_TRY(hipFree(ctx->fixed));
+        ctx->fixed = nullptr;
+        ctx->fixed_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->fixed), need));
+        ctx->fixed_bytes = need;
     }
+    HIP_TRY(hipMemsetAsync(ctx->fixed, 0, need, ctx->stream));
 
     caster::RenderArgs a;
     a.cam = cam_rec(cam);
@@ -394,7 +395,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     a.chunk = chunk; a.n_chunks = n_chunks;
     a.max_depth = max_depth;
     a.seed = seed;
-    a.slabs = ctx->slabs;
+    a.fixed = ctx->fixed;
     a.rays = ctx->rays_dev;
     a.queue = reinterpret_cast<unsigned int*>(ctx->rays_dev + 1);
     a.n_units = 0;
@@ -402,8 +403,8 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     if (flags & CASTER_HIP_STRICT) HIP_TRY(caster::launch_render_strict(a, ctx->resident_blocks, ctx->stream));
     else HIP_TRY(caster::launch_render_fast(a, ctx->resident_blocks, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(caster::launch_combine(ctx->slabs, n_chunks, (int)n_pixels, reinterpret_cast<float4*>(accum_dev),
-                                   ctx->stream));
+    HIP_TRY(caster::launch_fold(ctx->fixed, (int)n_pixels, sample_count, reinterpret_cast<float4*>(accum_dev),
+                                ctx->stream));
     return CASTER_HIP_OK;
 }
 

@@ -42,7 +42,7 @@ struct RenderArgs {
     int chunk, n_chunks;     // samples per work unit, units per pixel tile
     int max_depth;
     uint32_t seed;
-    float4* slabs;           // n_chunks * width * height partial sums
+    unsigned long long* fixed; // width * height * 4 fixed-point sums (2^-32 units), zero at launch
     unsigned long long* rays;
     unsigned int* queue;     // work-unit queue head, zero at launch
     int n_units;             // filled in by the launcher
@@ -77,7 +77,7 @@ CASTER_DECLARE_LAUNCHERS(strict)
 CASTER_DECLARE_LAUNCHERS(fast)
 
 // Mode-independent kernels (defined in the strict unit).
-hipError_t launch_combine(const float4* slabs, int n_chunks, int n_pixels, float4* accum, hipStream_t st);
+hipError_t launch_fold(const unsigned long long* fixed, int n_pixels, int sample_count, float4* accum, hipStream_t st);
 hipError_t launch_resolve(const float4* accum, int width, int height, int spp, uint8_t* rgba, hipStream_t st);
 hipError_t launch_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24, hipStream_t st);
 

@@ -19,8 +19,9 @@
 //   * the accumulators are 64-bit fixed point (2^-32 units): integer adds
 //     commute, so the sums do not depend on the order in which paths end and a
 //     render is bit-reproducible although the unit-to-wave assignment is not;
-//   * a finished unit's sums go to a slab private to its chunk; a later kernel
-//     adds the slabs in chunk order (no float atomics in global memory).
+//   * a finished unit's sums are added, still as integers, to a per-pixel
+//     fixed-point frame buffer in HBM (64-bit integer atomics: again order
+//     independent); a later kernel converts it to float once.
 //
 // Every ray is tested against every sphere (src/caster.c:204 has no early
 // out): the loop evaluates a conservative candidate test for both slots
@@ -165,16 +166,17 @@ CDEV void refill(Slot& s, Unit& un, int set, const RenderArgs& a, const Cam& cam
     un.next += __popcll(want);
 }
 
-// Writes a finished unit's sums to its chunk's slab and clears the accumulator set.
+// Adds a finished unit's sums to the frame's fixed-point buffer (4 words per pixel: R, G, B,
+// unused) and clears the accumulator set.
 CDEV void flush_unit(const Unit& un, acc_t* acc_set, const RenderArgs& a, int lane)
 {
     const int qx = lane & 7, qy = lane >> 3;
-    const float r = (float)((double)acc_set[lane * 3 + 0] * (1.0 / kAccScale));
-    const float g = (float)((double)acc_set[lane * 3 + 1] * (1.0 / kAccScale));
-    const float b = (float)((double)acc_set[lane * 3 + 2] * (1.0 / kAccScale));
     if (qx < un.tg.tw && qy < un.tg.th) {
-        const size_t px = (size_t)(un.tg.y0 + qy) * a.width + (un.tg.x0 + qx);
-        a.slabs[(size_t)un.chunk * a.width * a.height + px] = make_float4(r, g, b, (float)un.cs);
+        acc_t* px = a.fixed + 4 * ((size_t)(un.tg.y0 + qy) * a.width + (un.tg.x0 + qx));
+        const acc_t r = acc_set[lane * 3 + 0], g = acc_set[lane * 3 + 1], b = acc_set[lane * 3 + 2];
+        if (r) atomicAdd(px + 0, r);
+        if (g) atomicAdd(px + 1, g);
+        if (b) atomicAdd(px + 2, b);
     }
     acc_set[lane * 3 + 0] = 0; acc_set[lane * 3 + 1] = 0; acc_set[lane * 3 + 2] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -284,14 +286,38 @@ CDEV bool is_candidate(float key)
 CDEV void accept_one(const float4 e /* cx, cy, r*r, cz */, int index, const Slot& s, float& closest, int& best)
 {
 #if CASTER_STRICT
-    float root;
-    if (sphere_root(make_float4(e.x, e.y, e.w, e.z), s.o, s.d, s.aa, s.tmin, closest, root)) { closest = root; best = index; }
-#else
+    // The reference's arithmetic, operation for operation (src/caster.c:101-121), with two
+    // early returns that cannot change its outcome and spare most candidates the correctly
+    // rounded sqrt and divisions:
+    //  * hb >= 0 and c >= 0: then sqrt_d <= hb (sqrt(fl(hb*hb)) == hb exactly and the
+    //    discriminant is not larger), so both numerators are <= 0 and both roots fail
+    //    root < tmin (tmin > 0);
+    //  * -hb - sqrt_d > closest*a*(1 + 2^-21): then the correctly rounded quotient exceeds
+    //    closest, and so does the second root, whose numerator is not smaller.
     const float ocx = s.o.x - e.x, ocy = s.o.y - e.y, ocz = s.o.z - e.w;
-    const float hb = ocx * s.d.x + ocy * s.d.y + ocz * s.d.z;
-    const float c = ocx * ocx + ocy * ocy + ocz * ocz - e.z;
-    const float disc = hb * hb - c;                       // the direction has unit length
-    if (disc >= 0.0f) {
+    const float hb = (ocx * s.d.x + ocy * s.d.y) + ocz * s.d.z;
+    const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - e.z;
+    const float disc = hb * hb - s.aa * c;
+    if (disc < 0.0f) return;
+    if (hb >= 0.0f && c >= 0.0f) return;
+    const float sq = sqrtf(disc);
+    const float num1 = -hb - sq;
+    if (num1 > (closest * s.aa) * 1.0000005f) return;
+    float root = num1 / s.aa;
+    if (root < s.tmin || root > closest) {
+        root = (-hb + sq) / s.aa;
+        if (root < s.tmin || root > closest) return;
+    }
+    closest = root;
+    best = index;
+#else
+    // Explicit fmaf: this function is inlined once per slot, and a path must get the same
+    // bits in either slot, so the contraction pattern cannot be left to the compiler.
+    const float ocx = s.o.x - e.x, ocy = s.o.y - e.y, ocz = s.o.z - e.w;
+    const float hb = fmaf(ocz, s.d.z, fmaf(ocy, s.d.y, ocx * s.d.x));
+    const float c = fmaf(ocz, ocz, fmaf(ocy, ocy, fmaf(ocx, ocx, -e.z)));
+    const float disc = fmaf(hb, hb, -c);                  // the direction has unit length
+    if (disc >= 0.0f && (hb < 0.0f || c < 0.0f)) {
         const float sq = __builtin_amdgcn_sqrtf(disc);
         float root = -hb - sq;
         if (root < s.tmin || root > closest) root = -hb + sq;
@@ -492,16 +518,6 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     bool queue_empty = false;
 
     for (;;) {
-        // One copy of the per-slot code serves both slots (the slots trade places
-        // after each turn), so a path computes the same values in either slot.
-#pragma unroll 1
-        for (int k = 0; k < 2; ++k) {
-            bounce(sa, closestA, bestA, sc, wave_acc, rays);
-            swap_slots(sa, sb);
-            float tf = closestA; closestA = closestB; closestB = tf;
-            int ti = bestA; bestA = bestB; bestB = ti;
-        }
-
         // retire the previous unit once its last path has ended
         if (prev.chunk >= 0) {
             const int pset = set ^ 1;
@@ -522,10 +538,15 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
             queue_empty = cur.chunk < 0;
         }
 
+        // One copy of the per-slot code serves both slots (the slots trade places
+        // after each turn), so a path computes the same values in either slot.
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {
+            bounce(sa, closestA, bestA, sc, wave_acc, rays);
             refill(sa, cur, set, a, cam);
             swap_slots(sa, sb);
+            float tf = closestA; closestA = closestB; closestB = tf;
+            int ti = bestA; bestA = bestB; bestB = ti;
         }
 
         const int live = (sa.alive || sb.alive) ? 1 : 0;

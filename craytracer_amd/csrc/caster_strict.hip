@@ -7,17 +7,18 @@
 
 namespace caster {
 
-// accum[p] += slab[0][p] + slab[1][p] + ... in chunk order: the order is fixed,
-// so a render is bit-reproducible whatever order the units ran in.
-__global__ void k_combine(const float4* slabs, int n_chunks, int n_pixels, float4* accum)
+// accum[p] += the call's fixed-point sums, converted once; channel 3 counts samples.
+__global__ void k_fold(const unsigned long long* fixed, int n_pixels, int sample_count, float4* accum)
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
+    const ulonglong4 f = reinterpret_cast<const ulonglong4*>(fixed)[p];
+    const double k = 1.0 / 4294967296.0;
     float4 acc = accum[p];
-    for (int c = 0; c < n_chunks; ++c) {
-        const float4 s = slabs[(size_t)c * n_pixels + p];
-        acc.x = acc.x + s.x; acc.y = acc.y + s.y; acc.z = acc.z + s.z; acc.w = acc.w + s.w;
-    }
+    acc.x = acc.x + (float)((double)f.x * k);
+    acc.y = acc.y + (float)((double)f.y * k);
+    acc.z = acc.z + (float)((double)f.z * k);
+    acc.w = acc.w + (float)sample_count;
     accum[p] = acc;
 }
 
@@ -47,10 +48,10 @@ __global__ void k_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n
     for (int k = 0; k < n; ++k) out24[k] = rng_next24(g);
 }
 
-hipError_t launch_combine(const float4* slabs, int n_chunks, int n_pixels, float4* accum, hipStream_t st)
+hipError_t launch_fold(const unsigned long long* fixed, int n_pixels, int sample_count, float4* accum, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_combine, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, st, slabs, n_chunks,
-                       n_pixels, accum);
+    hipLaunchKernelGGL(k_fold, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, st, fixed, n_pixels,
+                       sample_count, accum);
     return hipGetLastError();
 }
 

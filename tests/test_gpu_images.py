@@ -76,6 +76,25 @@ def test_odd_sizes_and_chunks(gpu, orc, ca):
     assert np.array_equal(g2, ref)          # bit-reproducible run to run
 
 
+def test_fast_mode_is_scheduling_independent(gpu, ca):
+    """Work units go to whichever wave is free, and a path may run in either of a lane's two slots:
+    neither may change a single bit of the image, in fast mode as well (640k paths, so that a rare
+    slot- or order-dependent rounding would show)."""
+    fs = ca.scene_rtiow(1)
+    gpu.upload_scene(fs)
+    w, h, spp, depth, seed = 200, 100, 32, 50, 77
+    cam = ca.default_camera(w / h)
+    ref, ref_rays = None, None
+    for chunk in (0, 0, 5, 32):
+        gpu.set_chunk(chunk)
+        s, rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=False)
+        if ref is None:
+            ref, ref_rays = s, rays
+        assert rays == ref_rays
+        assert np.array_equal(s, ref)
+    gpu.set_chunk(0)
+
+
 def test_sample_partitions_sum_to_the_frame(gpu, orc, ca):
     """Per-GPU sample partitions [g*spp/G, (g+1)*spp/G): same paths, sums add up."""
     fs = ca.scene_rtiow(1)
