@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s and ms/frame of the per-pixel path-tracing path on MI355X.
 
-Workload (BASELINE.json configs[1]): the "Ray Tracing in One Weekend" final random-spheres
+Workload: the "Ray Tracing in One Weekend" final random-spheres
 scene (487 spheres incl. ground and an enclosing emissive sky sphere), 1920x1080, 500 samples
 per pixel, max depth 50, brute-force closest hit over the whole sphere list as the reference
 does.  One step = one frame: every rank renders its sample partition of all pixels into a

@@ -1,7 +1,7 @@
 """Per-function parity of the HIP device functions (strict arithmetic mode) with the CPU
 restatement of the reference functions, called through the C ABI's array entry points.
 
-Bar (BASELINE north_star): t, normal and scatter direction within 2 ULP-scaled FP32 on
+Bar: t, normal and scatter direction within 2 ULP-scaled FP32 on
 identical inputs.  Everything that involves only +,-,*,/ and sqrt is in fact expected to be
 bit-identical; libm-backed results (Schlick powf, uv atan2/acos) may differ in the last place.
 """

@@ -1,6 +1,6 @@
 """Whole-image parity of the HIP path with the CPU restatement on the shared counter RNG.
 
-Bar (BASELINE north_star): with the same random stream images agree pixel for pixel within
+Bar: with the same random stream images agree pixel for pixel within
 1e-4 relative error (strict arithmetic mode); ray counts are integers and must be equal.
 The only arithmetic difference by design is the order of the throughput product: the
 reference multiplies c1*(c2*(...*emit)) on the way out of its recursion, the iterative
@@ -140,7 +140,7 @@ def test_empty_and_degenerate_inputs(gpu, ca):
 def test_fast_mode_statistically_equal(gpu, orc, ca):
     """Fast arithmetic (FMA, reordered ops) renders the same image up to Monte-Carlo noise: at
     equal seeds almost every path is identical, so the images are far closer than the
-    PSNR > 45 dB / mean-abs-error < 1/255 bar that BASELINE sets against unmodified CRaytracer."""
+    PSNR > 45 dB / mean-abs-error < 1/255 bar set for images against unmodified CRaytracer."""
     fs = ca.scene_rtiow(1)
     gpu.upload_scene(fs)
     w, h, spp, depth, seed = 96, 54, 64, 50, 1234
