@@ -38,7 +38,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWaves = kBlock / 64;
-constexpr int kSphTile = 1024;              // spheres staged in LDS at a time (16 KiB)
+constexpr int kSphTile = 512;               // spheres staged in LDS at a time (two 8 KiB images)
+constexpr int kMaxCand = 8;                 // deferred candidates per slot and lane before the list is worked off
 constexpr int kTileW = 8, kTileH = 8;       // pixels per work unit
 
 CDEV f2 splat(float x) { return f2{x, x}; }
@@ -103,6 +104,8 @@ struct Unit {
 
 constexpr int kAccStride = kTileW * kTileH * 3;     // one accumulator set: 64 pixels x RGB
 typedef unsigned long long acc_t;                   // fixed point, 32 fractional bits
+// LDS in front of the sphere images: accumulators, then the candidate lists
+constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * 2 * kAccStride + 2 * kWaves * 2 * kMaxCand * 64;
 constexpr double kAccScale = 4294967296.0;
 
 // Pulls the next unit off the queue.  Units are numbered chunk-major.
@@ -326,17 +329,52 @@ CDEV void accept_one(const float4 e /* cx, cy, r*r, cz */, int index, const Slot
 #endif
 }
 
-// One sphere whose filter operands f are already in registers; k is its
-// position in the LDS tile, index its position in the scene's sphere array.
-CDEV void process_sphere(const float4 f, const SphereLds& lds, int k, int index, const PairRays& r,
+// Candidates are not examined where they are found: a sphere is a candidate for a handful
+// of the wave's 128 rays at most, and the reference's root/closest-hit arithmetic (sqrt, two
+// divisions) would run for the whole wave each time.  Instead every lane appends the sphere's
+// tile position to a short list per slot (LDS, lane-minor), and the lists are worked off
+// together after the tile: trip i of that loop handles every lane's i-th candidate at once,
+// in list order, which is the reference's object order (src/caster.c:204-215).
+struct CandLists {
+    unsigned short* mem;    // [2 slots][kMaxCand][64 lanes], this wave's
+    int lane;
+    int cntA, cntB;         // entries of this lane
+};
+
+CDEV void push_candidate(CandLists& cl, int slot, int& cnt, int k)
+{
+    cl.mem[(slot * kMaxCand + cnt) * 64 + cl.lane] = (unsigned short)k;
+    cnt++;
+}
+
+CDEV void drain_candidates(CandLists& cl, const SphereLds& lds, int base, const Slot& sa, const Slot& sb,
+                           float& closestA, float& closestB, int& bestA, int& bestB)
+{
+    for (int i = 0; __any((i < cl.cntA) | (i < cl.cntB)); ++i) {
+        if (i < cl.cntA) {
+            const int k = cl.mem[(0 * kMaxCand + i) * 64 + cl.lane];
+            accept_one(lds.exact[k], base + k, sa, closestA, bestA);
+        }
+        if (i < cl.cntB) {
+            const int k = cl.mem[(1 * kMaxCand + i) * 64 + cl.lane];
+            accept_one(lds.exact[k], base + k, sb, closestB, bestB);
+        }
+    }
+    cl.cntA = 0;
+    cl.cntB = 0;
+}
+
+// One sphere whose filter operands f are already in registers; k is its position in the LDS tile.
+CDEV void process_sphere(const float4 f, int k, const PairRays& r, CandLists& cl, const SphereLds& lds, int base,
                          const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
     const f2 key = candidate_key(r, f);
     // one branch for the pair of slots; `|` instead of `||` keeps it a single test
     if (is_candidate(key.x) | is_candidate(key.y)) {
-        const float4 e = lds.exact[k];
-        if (is_candidate(key.x)) accept_one(e, index, sa, closestA, bestA);
-        if (is_candidate(key.y)) accept_one(e, index, sb, closestB, bestB);
+        if (is_candidate(key.x)) push_candidate(cl, 0, cl.cntA, k);
+        if (is_candidate(key.y)) push_candidate(cl, 1, cl.cntB, k);
+        if (__any((cl.cntA >= kMaxCand) | (cl.cntB >= kMaxCand)))       // a list is full: work them off now
+            drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
     }
 }
 
@@ -359,34 +397,35 @@ CDEV Group load_group(const float4* src, int k)
     return g;
 }
 
-CDEV void process_group(const Group& g, const SphereLds& lds, int k, int index, const PairRays& r,
+CDEV void process_group(const Group& g, int k, const PairRays& r, CandLists& cl, const SphereLds& lds, int base,
                         const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
-    process_sphere(g.g0, lds, k, index, r, sa, sb, closestA, closestB, bestA, bestB);
-    process_sphere(g.g1, lds, k + 1, index + 1, r, sa, sb, closestA, closestB, bestA, bestB);
+    process_sphere(g.g0, k, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+    process_sphere(g.g1, k + 1, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
 #if !CASTER_STRICT
-    process_sphere(g.g2, lds, k + 2, index + 2, r, sa, sb, closestA, closestB, bestA, bestB);
-    process_sphere(g.g3, lds, k + 3, index + 3, r, sa, sb, closestA, closestB, bestA, bestB);
+    process_sphere(g.g2, k + 2, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+    process_sphere(g.g3, k + 3, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
 #endif
 }
 
 // Sphere loop over one LDS tile for the two slots of a lane.  cnt is a
 // multiple of 2*kGroup (the tile is padded) and kLdsSlack entries beyond it are
 // readable.  Two register sets alternate: while one group is evaluated the
-// next one is already on its way from LDS.  closest / best are updated as the
-// reference's in-order loop does (src/caster.c:204-215).
-CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, const Slot& sa, const Slot& sb,
-                     float& closestA, float& closestB, int& bestA, int& bestB)
+// next one is already on its way from LDS.  On return the candidate lists are
+// empty and closest / best hold what the reference's in-order loop would hold.
+CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, CandLists& cl,
+                     const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
     const float4* src = lds.filter;
     Group ga = load_group(src, 0);
 #pragma unroll 1
     for (int k = 0; k < cnt; k += 2 * kGroup) {
         const Group gb = load_group(src, k + kGroup);
-        process_group(ga, lds, k, base + k, r, sa, sb, closestA, closestB, bestA, bestB);
+        process_group(ga, k, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
         ga = load_group(src, k + 2 * kGroup);
-        process_group(gb, lds, k + kGroup, base + k + kGroup, r, sa, sb, closestA, closestB, bestA, bestB);
+        process_group(gb, k + kGroup, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
     }
+    drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
 }
 
 // Copies spheres [base, base+cnt) into LDS, padded to a multiple of 2*kGroup
@@ -473,9 +512,11 @@ __global__ __launch_bounds__(kBlock, 4)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    // layout: accumulators [kWaves][2][kAccStride] (acc_t), then the two sphere images
+    // layout: accumulators [kWaves][2][kAccStride] (acc_t), candidate lists [kWaves][2][kMaxCand][64]
+    // (u16), then the two sphere images
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
-    float4* s_exact = reinterpret_cast<float4*>(s_dyn + sizeof(acc_t) * kWaves * 2 * kAccStride);
+    unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_dyn + sizeof(acc_t) * kWaves * 2 * kAccStride);
+    float4* s_exact = reinterpret_cast<float4*>(s_dyn + kLdsFixedBytes);
     float4* s_filter = s_exact + a.lds_spheres;
 
     const SceneView sc = view_of(a.scene);
@@ -507,6 +548,11 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     unsigned int rays = 0;
     float closestA = kTMax, closestB = kTMax;
     int bestA = -1, bestB = -1;
+
+    CandLists cl;
+    cl.mem = s_cand + wave * 2 * kMaxCand * 64;
+    cl.lane = lane;
+    cl.cntA = cl.cntB = 0;
 
     Unit cur, prev;                 // cur feeds the slots; prev only waits for its last paths
     cur.chunk = prev.chunk = -1;
@@ -567,7 +613,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         bestA = -1; bestB = -1;
         const PairRays pr = pack_rays(sa, sb, ref);
         if (!TILED) {
-            isect_tile(lds, n_lds, 0, pr, sa, sb, closestA, closestB, bestA, bestB);
+            isect_tile(lds, n_lds, 0, pr, cl, sa, sb, closestA, closestB, bestA, bestB);
         } else {
             for (int base = 0; base < sc.n_sph; base += kSphTile) {
                 const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
@@ -575,7 +621,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
                 const int padded = stage_spheres(s_exact, s_filter, sc, base, cnt);
                 lds.count = cnt;
                 __syncthreads();
-                isect_tile(lds, padded, base, pr, sa, sb, closestA, closestB, bestA, bestB);
+                isect_tile(lds, padded, base, pr, cl, sa, sb, closestA, closestB, bestA, bestB);
             }
         }
     }
@@ -601,7 +647,7 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     if (units <= 0 || units > 0x7fffffffLL) return hipErrorInvalidValue;
     a.n_units = (int)units;
     a.lds_spheres = lds_sphere_slots(a.scene.n_sph);
-    const size_t lds_bytes = sizeof(acc_t) * kWaves * 2 * kAccStride + 2 * sizeof(float4) * (size_t)a.lds_spheres;
+    const size_t lds_bytes = kLdsFixedBytes + 2 * sizeof(float4) * (size_t)a.lds_spheres;
     long long blocks = (units + kWaves - 1) / kWaves;
     if (blocks > resident_blocks) blocks = resident_blocks;      // persistent: the waves loop over the queue
     if (a.scene.n_sph > kSphTile)
@@ -620,6 +666,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
 {
     __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
     __shared__ float4 s_filter[kSphTile + 2 * kLdsSlack];
+    __shared__ unsigned short s_cand[kWaves * 2 * kMaxCand * 64];
     const SceneView sc = view_of(sd);
     SphereLds lds;
     lds.exact = s_exact;
@@ -648,13 +695,17 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
     float closest[2] = {sl[0].tmax, sl[1].tmax};
     int best[2] = {-1, -1};
     const PairRays pr = pack_rays(sl[0], sl[1], ref);
+    CandLists cl;
+    cl.mem = s_cand + (threadIdx.x >> 6) * 2 * kMaxCand * 64;
+    cl.lane = threadIdx.x & 63;
+    cl.cntA = cl.cntB = 0;
     for (int base = 0; base < sc.n_sph; base += kSphTile) {
         const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
         __syncthreads();
         const int padded = stage_spheres(s_exact, s_filter, sc, base, cnt);
         lds.count = cnt;
         __syncthreads();
-        isect_tile(lds, padded, base, pr, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
+        isect_tile(lds, padded, base, pr, cl, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
     }
     for (int k = 0; k < 2; ++k) {
         if (i0 + k >= n) continue;
