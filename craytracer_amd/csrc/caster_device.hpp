@@ -17,6 +17,21 @@
 
 #define CDEV __device__ __forceinline__
 
+// Developer statistics build (-DCASTER_STATS): wave-level event counters.  Off in the product.
+#ifdef CASTER_STATS
+__device__ unsigned long long g_caster_stats[32];
+#define CASTER_STAT(i)                                                                                   \
+    do {                                                                                                 \
+        const unsigned long long ex_ = __builtin_amdgcn_read_exec();                                     \
+        if (__builtin_amdgcn_mbcnt_hi((unsigned)(ex_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ex_, 0u)) == 0) \
+            atomicAdd(&g_caster_stats[i], 1ull);                                                         \
+    } while (0)
+#define CASTER_STAT_LANES(i) atomicAdd(&g_caster_stats[i], 1ull)
+#else
+#define CASTER_STAT(i) do { } while (0)
+#define CASTER_STAT_LANES(i) do { } while (0)
+#endif
+
 namespace caster {
 
 constexpr float kPi = 3.141592654f;      // inc/common.h:10
@@ -121,6 +136,7 @@ CDEV float random_range_f32(Rng& g, float lo, float hi)         // common.c:15-1
 CDEV V3 random_unit_sphere(Rng& g)                              // common.c:108-126
 {
     for (;;) {
+        CASTER_STAT(4);
         V3 p;
         p.x = random_range_f32(g, -1.0f, 1.0f);
         p.y = random_range_f32(g, -1.0f, 1.0f);
@@ -132,6 +148,7 @@ CDEV V3 random_unit_sphere(Rng& g)                              // common.c:108-
 CDEV V3 random_unit_disk(Rng& g)                                // common.c:128-136, x first
 {
     for (;;) {
+        CASTER_STAT(5);
         V3 p;
         p.x = random_range_f32(g, -1.0f, 1.0f);
         p.y = random_range_f32(g, -1.0f, 1.0f);
@@ -395,12 +412,14 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
     if (m.type == 0 || m.type == 1) us = random_unit_sphere(g);
     switch (m.type) {
     case 0: // MTYPE_LAMBERTIAN, material.c:3-12
+        CASTER_STAT(7);
         next.o = rec.p;
         next.d = rec.n + to_unit(us);
         if (near_zero(next.d)) next.d = rec.n;
         atten = texture_color(sc, m, rec);
         return true;
     case 1: // MTYPE_METAL, material.c:14-19
+        CASTER_STAT(8);
         next.o = rec.p;
         next.d = reflect(to_unit(r.d), rec.n) + us * m.fuzz;
         if (dot(next.d, rec.n) > 0.0f) {
@@ -409,9 +428,11 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
         }
         return false;
     case 2: // MTYPE_DIELECTRIC
+        CASTER_STAT(9);
         scatter_dielectric(g, r, rec, m.ior, next);
         return true;
     case 3: // MTYPE_DIFF_LIGHT
+        CASTER_STAT(10);
         if (m.tex == 0) emit = mk(m.c0[0], m.c0[1], m.c0[2]);
         else if (m.tex == 2) emit = texture_color(sc, m, rec);
         return false;

@@ -207,6 +207,18 @@ __global__ void CASTER_NAME(k_test_texture_)(SceneDev sd, int n, const int32_t* 
     rgb3[3 * k] = c.x; rgb3[3 * k + 1] = c.y; rgb3[3 * k + 2] = c.z;
 }
 
+#ifdef CASTER_STATS
+extern "C" void CASTER_NAME(caster_debug_stats_)(unsigned long long* out32, int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_caster_stats), sizeof(unsigned long long) * 32);
+    if (reset) {
+        unsigned long long z[32] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_caster_stats), z, sizeof z);
+    }
+}
+#endif
+
 static inline dim3 grid_for(int n) { return dim3((unsigned)((n + 255) / 256)); }
 
 hipError_t CASTER_NAME(launch_test_hit_sphere_)(int n, const float* sph4, const float* ray6, const float* tr2,

@@ -165,7 +165,7 @@ CDEV void refill(Slot& s, Unit& un, int set, const RenderArgs& a, const Cam& cam
     if (want == 0ull) return;
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
     const int m = un.next + rank;
-    if (!s.alive && m < un.total) start_pool_path(s, m, un, set, a, cam);
+    if (!s.alive && m < un.total) { CASTER_STAT(11); start_pool_path(s, m, un, set, a, cam); }
     un.next += __popcll(want);
 }
 
@@ -241,6 +241,7 @@ struct SphereLds {
 
 struct PairRays {     // filter operands of both slots of a lane, packed
     f2 p2x, p2y, p2z, ndx, ndy, ndz, od, base;
+    float force;      // +inf if either ray is not finite (every sphere is then a candidate), else -inf
 };
 
 CDEV PairRays pack_rays(const Slot& sa, const Slot& sb, const float3 ref)
@@ -261,6 +262,10 @@ CDEV PairRays pack_rays(const Slot& sa, const Slot& sb, const float3 ref)
     r.p2x = qx + qx; r.p2y = qy + qy; r.p2z = qz + qz;
     r.ndx = -ux; r.ndy = -uy; r.ndz = -uz;
     r.base = oo * splat(kFilterMargin - 1.0f);
+    // o'.o' and o'.u are finite exactly when every component of both rays is (overflow aside,
+    // which makes the ray a candidate everywhere: conservative)
+    const float probe = (oo.x + oo.y) + (r.od.x + r.od.y);
+    r.force = (probe - probe == 0.0f) ? -INFINITY : INFINITY;
     return r;
 }
 
@@ -351,11 +356,14 @@ CDEV void drain_candidates(CandLists& cl, const SphereLds& lds, int base, const 
                            float& closestA, float& closestB, int& bestA, int& bestB)
 {
     for (int i = 0; __any((i < cl.cntA) | (i < cl.cntB)); ++i) {
+        CASTER_STAT(1);
         if (i < cl.cntA) {
+            CASTER_STAT(2);
             const int k = cl.mem[(0 * kMaxCand + i) * 64 + cl.lane];
             accept_one(lds.exact[k], base + k, sa, closestA, bestA);
         }
         if (i < cl.cntB) {
+            CASTER_STAT(3);
             const int k = cl.mem[(1 * kMaxCand + i) * 64 + cl.lane];
             accept_one(lds.exact[k], base + k, sb, closestB, bestB);
         }
@@ -364,15 +372,14 @@ CDEV void drain_candidates(CandLists& cl, const SphereLds& lds, int base, const 
     cl.cntB = 0;
 }
 
-// One sphere whose filter operands f are already in registers; k is its position in the LDS tile.
-CDEV void process_sphere(const float4 f, int k, const PairRays& r, CandLists& cl, const SphereLds& lds, int base,
+// Appends sphere k to the lists of the slots for which it is a candidate.
+CDEV void note_candidate(const f2 key, int k, CandLists& cl, const SphereLds& lds, int base,
                          const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
-    const f2 key = candidate_key(r, f);
-    // one branch for the pair of slots; `|` instead of `||` keeps it a single test
     if (is_candidate(key.x) | is_candidate(key.y)) {
-        if (is_candidate(key.x)) push_candidate(cl, 0, cl.cntA, k);
-        if (is_candidate(key.y)) push_candidate(cl, 1, cl.cntB, k);
+        CASTER_STAT(12);
+        if (is_candidate(key.x)) { CASTER_STAT_LANES(13); push_candidate(cl, 0, cl.cntA, k); }
+        if (is_candidate(key.y)) { CASTER_STAT_LANES(13); push_candidate(cl, 1, cl.cntB, k); }
         if (__any((cl.cntA >= kMaxCand) | (cl.cntB >= kMaxCand)))       // a list is full: work them off now
             drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
     }
@@ -397,15 +404,32 @@ CDEV Group load_group(const float4* src, int k)
     return g;
 }
 
-CDEV void process_group(const Group& g, int k, const PairRays& r, CandLists& cl, const SphereLds& lds, int base,
-                        const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
+// Evaluates the candidate keys of a group and looks at them together: a sphere is a candidate
+// for some ray of the wave only a few percent of the time, so one test of the group's largest
+// key (max3 chain) replaces two compares per sphere.  `force` is +inf for a lane whose ray is
+// not finite (its keys are NaN, which max3 would drop) and -inf otherwise.
+CDEV void process_group(const Group& g, int k, const PairRays& r, float force, CandLists& cl, const SphereLds& lds,
+                        int base, const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA,
+                        int& bestB)
 {
-    process_sphere(g.g0, k, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
-    process_sphere(g.g1, k + 1, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+    const f2 k0 = candidate_key(r, g.g0);
+    const f2 k1 = candidate_key(r, g.g1);
+    float m = __builtin_fmaxf(__builtin_fmaxf(k0.x, k0.y), force);
+    m = __builtin_fmaxf(__builtin_fmaxf(k1.x, k1.y), m);
 #if !CASTER_STRICT
-    process_sphere(g.g2, k + 2, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
-    process_sphere(g.g3, k + 3, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+    const f2 k2 = candidate_key(r, g.g2);
+    const f2 k3 = candidate_key(r, g.g3);
+    m = __builtin_fmaxf(__builtin_fmaxf(k2.x, k2.y), m);
+    m = __builtin_fmaxf(__builtin_fmaxf(k3.x, k3.y), m);
 #endif
+    if (m >= 0.0f) {
+        note_candidate(k0, k, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        note_candidate(k1, k + 1, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+#if !CASTER_STRICT
+        note_candidate(k2, k + 2, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        note_candidate(k3, k + 3, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+#endif
+    }
 }
 
 // Sphere loop over one LDS tile for the two slots of a lane.  cnt is a
@@ -417,13 +441,14 @@ CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, 
                      const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
     const float4* src = lds.filter;
+    const float force = r.force;
     Group ga = load_group(src, 0);
 #pragma unroll 1
     for (int k = 0; k < cnt; k += 2 * kGroup) {
         const Group gb = load_group(src, k + kGroup);
-        process_group(ga, k, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        process_group(ga, k, r, force, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
         ga = load_group(src, k + 2 * kGroup);
-        process_group(gb, k + kGroup, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        process_group(gb, k + kGroup, r, force, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
     }
     drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
 }
@@ -471,6 +496,7 @@ CDEV bool resolve_hit(const Slot& s, const Ray& r, float closest, int best_sph, 
 CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, acc_t* wave_acc, unsigned int& rays)
 {
     if (!s.alive) return;
+    CASTER_STAT(6);
     rays++;
     Ray r;
     r.o = s.o;
@@ -609,6 +635,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
             }
         }
 
+        CASTER_STAT(0);
         closestA = sa.tmax; closestB = sb.tmax;
         bestA = -1; bestB = -1;
         const PairRays pr = pack_rays(sa, sb, ref);
