@@ -214,11 +214,10 @@ CDEV acc_t to_fixed(float x)
 // then decides is exactly what the reference decides (strict mode) or the same
 // test on the unit direction (fast mode).  Spheres much larger than the rest
 // (ground, sky) carry +inf and are always candidates.
+constexpr int kGroup = 4;               // spheres per software-pipeline stage
 #if CASTER_STRICT
-constexpr int kGroup = 2;               // spheres per software-pipeline stage (the strict candidate code needs the registers)
 constexpr float kFilterMargin = 1.0e-5f;
 #else
-constexpr int kGroup = 4;
 constexpr float kFilterMargin = 2.5e-6f;
 #endif
 constexpr int kLdsSlack = 2 * kGroup;   // read-ahead beyond the padded tile
@@ -388,19 +387,14 @@ CDEV void note_candidate(const f2 key, int k, CandLists& cl, const SphereLds& ld
 // A pipeline stage: kGroup spheres held in named registers (no indexed array,
 // so nothing can end up in scratch memory).
 struct Group {
-    float4 g0, g1;
-#if !CASTER_STRICT
-    float4 g2, g3;
-#endif
+    float4 g0, g1, g2, g3;
 };
 
 CDEV Group load_group(const float4* src, int k)
 {
     Group g;
     g.g0 = src[k]; g.g1 = src[k + 1];
-#if !CASTER_STRICT
     g.g2 = src[k + 2]; g.g3 = src[k + 3];
-#endif
     return g;
 }
 
@@ -416,19 +410,15 @@ CDEV void process_group(const Group& g, int k, const PairRays& r, float force, C
     const f2 k1 = candidate_key(r, g.g1);
     float m = __builtin_fmaxf(__builtin_fmaxf(k0.x, k0.y), force);
     m = __builtin_fmaxf(__builtin_fmaxf(k1.x, k1.y), m);
-#if !CASTER_STRICT
     const f2 k2 = candidate_key(r, g.g2);
     const f2 k3 = candidate_key(r, g.g3);
     m = __builtin_fmaxf(__builtin_fmaxf(k2.x, k2.y), m);
     m = __builtin_fmaxf(__builtin_fmaxf(k3.x, k3.y), m);
-#endif
     if (m >= 0.0f) {
         note_candidate(k0, k, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
         note_candidate(k1, k + 1, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
-#if !CASTER_STRICT
         note_candidate(k2, k + 2, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
         note_candidate(k3, k + 3, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
-#endif
     }
 }
 
