@@ -257,9 +257,12 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
     // Candidate filter tables (see caster_render.hpp): reference point P = mean
     // centre of the ordinary spheres; per sphere c' = c - P, K = |c'|^2 - r*r and
     // the error scale |c'|^2 + r*r.  A sphere much larger than the median one
-    // gets K = -inf: it is always a candidate.
+    // is a candidate for every ray: the first few of them are listed in `always`
+    // and tested directly (K = +inf keeps them out of the filter), the others
+    // get K = -inf.
     std::vector<float4> sph_filter(sph.size());
     std::vector<float> sph_scale(sph.size());
+    ctx->scene.n_always = 0;
     double ref[3] = {0.0, 0.0, 0.0};
     if (!sph.empty()) {
         std::vector<float> radii;
@@ -271,13 +274,16 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
             if (fabs((double)q.w) <= huge_r) { ref[0] += q.x; ref[1] += q.y; ref[2] += q.z; ++n_ord; }
         if (n_ord) { ref[0] /= (double)n_ord; ref[1] /= (double)n_ord; ref[2] /= (double)n_ord; }
         const float pf[3] = {(float)ref[0], (float)ref[1], (float)ref[2]};
+        ctx->scene.n_always = 0;
         for (size_t k = 0; k < sph.size(); ++k) {
             const float4 q = sph[k];
             const float cx = q.x - pf[0], cy = q.y - pf[1], cz = q.z - pf[2];
             const double C = (double)cx * cx + (double)cy * cy + (double)cz * cz;
             const double r2 = (double)q.w * (double)q.w;
             const bool huge = !(fabs((double)q.w) <= huge_r) || !std::isfinite(C) || !std::isfinite(r2);
-            sph_filter[k] = make_float4(cx, cy, cz, huge ? -INFINITY : (float)(C - r2));
+            const bool direct = huge && ctx->scene.n_always < caster::kMaxAlways;
+            if (direct) ctx->scene.always[ctx->scene.n_always++] = (int)k;
+            sph_filter[k] = make_float4(cx, cy, cz, direct ? INFINITY : huge ? -INFINITY : (float)(C - r2));
             sph_scale[k] = huge ? 0.0f : (float)(C + r2);
         }
         ref[0] = pf[0]; ref[1] = pf[1]; ref[2] = pf[2];
@@ -353,6 +359,42 @@ int caster_hip_synchronize(caster_hip_ctx* ctx)
     return CASTER_HIP_OK;
 }
 
+// Splits the sample range of a call into the chunks of the work units (unit = 8x8 pixel tile x chunk;
+// the queue hands the units out chunk by chunk).  Large chunks keep a wave's path slots full: a wave
+// moves on to its next unit while the last paths of the previous one finish, but holds only two units at a
+// time.  Smaller chunks at the end keep the waves from finishing far apart (a unit of 128 samples in a
+// costly part of the frame takes several percent of a 500-sample frame's time).  So: equal large
+// chunks first, then halves down to 16 samples.  The sums are integers, so the split does not change the result.
+static int plan_chunks(const caster_hip_ctx* ctx, int width, int height, int sample_count, int* start)
+{
+    const int cap = caster::kMaxChunks;
+    int n = 0;
+    start[0] = 0;
+    if (ctx->chunk > 0) {           // caller's choice: equal chunks
+        int chunk = ctx->chunk;
+        if ((sample_count + chunk - 1) / chunk > cap) chunk = (sample_count + cap - 1) / cap;
+        for (int s = 0; s < sample_count; s += chunk) start[++n] = (s + chunk < sample_count) ? s + chunk : sample_count;
+        return n;
+    }
+    const long long tiles = (long long)((width + 7) / 8) * ((height + 7) / 8);
+    const long long waves = (long long)ctx->resident_blocks * 4;
+    long long bulk = (long long)sample_count * tiles / (16 * waves);     // >= 16 units per wave if the job allows it
+    if (bulk > 128) bulk = 128;
+    if (bulk < 8) bulk = 8;
+    if ((sample_count + bulk - 1) / bulk > cap - 16) bulk = (sample_count + cap - 17) / (cap - 16);
+    int left = sample_count;
+    while (left > 0) {
+        int c = (left + 1) / 2;
+        if (c > bulk) c = (int)bulk;
+        if (c < 16) c = 16;
+        if (c > left || n == cap - 1) c = left;
+        start[n + 1] = start[n] + c;
+        ++n;
+        left -= c;
+    }
+    return n;
+}
+
 int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height,
                       int sample_begin, int sample_count, int max_depth,
                       uint32_t seed, uint32_t flags, float* accum_dev)
@@ -372,9 +414,6 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
         return CASTER_HIP_OK;
     }
 
-    int chunk = ctx->chunk > 0 ? ctx->chunk : 32;
-    if (chunk > sample_count) chunk = sample_count;
-    const int n_chunks = (sample_count + chunk - 1) / chunk;
     const size_t n_pixels = (size_t)width * height;
     const size_t need = n_pixels * 4 * sizeof(unsigned long long);
     if (need > ctx->fixed_bytes) {
@@ -392,7 +431,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     a.scene = ctx->scene;
     a.width = width; a.height = height;
     a.s_begin = sample_begin; a.s_count = sample_count;
-    a.chunk = chunk; a.n_chunks = n_chunks;
+    a.n_chunks = plan_chunks(ctx, width, height, sample_count, a.chunk_start);
     a.max_depth = max_depth;
     a.seed = seed;
     a.fixed = ctx->fixed;

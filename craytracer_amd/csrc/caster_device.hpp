@@ -17,19 +17,32 @@
 
 #define CDEV __device__ __forceinline__
 
-// Developer statistics build (-DCASTER_STATS): wave-level event counters.  Off in the product.
-#ifdef CASTER_STATS
+// Developer builds, off in the product: -DCASTER_STATS counts wave-level events, -DCASTER_TIMERS sums the
+// shader clock ticks the waves spend in regions of the render kernel (slot 16+i).
+#if defined(CASTER_STATS) || defined(CASTER_TIMERS)
 __device__ unsigned long long g_caster_stats[32];
+#endif
+#ifdef CASTER_STATS
 #define CASTER_STAT(i)                                                                                   \
     do {                                                                                                 \
         const unsigned long long ex_ = __builtin_amdgcn_read_exec();                                     \
         if (__builtin_amdgcn_mbcnt_hi((unsigned)(ex_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ex_, 0u)) == 0) \
             atomicAdd(&g_caster_stats[i], 1ull);                                                         \
     } while (0)
-#define CASTER_STAT_LANES(i) atomicAdd(&g_caster_stats[i], 1ull)
 #else
 #define CASTER_STAT(i) do { } while (0)
-#define CASTER_STAT_LANES(i) do { } while (0)
+#endif
+#ifdef CASTER_TIMERS
+__device__ unsigned long long g_caster_wavelog[4096 * 16];   // per resident wave: start, end (100 MHz), units, trips, last fetch time, last unit, time the queue was found empty, trips then
+#define CASTER_TIC(v) const unsigned long long v = __builtin_readcyclecounter()
+#define CASTER_TOC(v, acc) acc += __builtin_readcyclecounter() - v
+#define CASTER_TIME_DECL(acc) unsigned long long acc = 0
+#define CASTER_TIME_OUT(acc, i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_caster_stats[16 + (i)], acc); } while (0)
+#else
+#define CASTER_TIC(v) do { } while (0)
+#define CASTER_TOC(v, acc) do { } while (0)
+#define CASTER_TIME_DECL(acc) do { } while (0)
+#define CASTER_TIME_OUT(acc, i) do { } while (0)
 #endif
 
 namespace caster {
@@ -69,6 +82,8 @@ struct SceneView {
     const Mat*    mats;
     const Img*    imgs;
     int n_sph, n_rect, n_mat, n_img;
+    int n_always;
+    int always[4];          // spheres tested directly for every ray
 };
 
 CDEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }

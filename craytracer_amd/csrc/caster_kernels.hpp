@@ -24,6 +24,8 @@ CDEV SceneView view_of(const SceneDev& s)
     v.mats = reinterpret_cast<const Mat*>(s.mats);
     v.imgs = reinterpret_cast<const Img*>(s.imgs);
     v.n_sph = s.n_sph; v.n_rect = s.n_rect; v.n_mat = s.n_mat; v.n_img = s.n_img;
+    v.n_always = s.n_always;
+    for (int k = 0; k < kMaxAlways; ++k) v.always[k] = s.always[k];
     return v;
 }
 
@@ -207,7 +209,7 @@ __global__ void CASTER_NAME(k_test_texture_)(SceneDev sd, int n, const int32_t* 
     rgb3[3 * k] = c.x; rgb3[3 * k + 1] = c.y; rgb3[3 * k + 2] = c.z;
 }
 
-#ifdef CASTER_STATS
+#if defined(CASTER_STATS) || defined(CASTER_TIMERS)
 extern "C" void CASTER_NAME(caster_debug_stats_)(unsigned long long* out32, int reset)
 {
     (void)hipDeviceSynchronize();
@@ -216,6 +218,13 @@ extern "C" void CASTER_NAME(caster_debug_stats_)(unsigned long long* out32, int 
         unsigned long long z[32] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_caster_stats), z, sizeof z);
     }
+}
+#endif
+#ifdef CASTER_TIMERS
+extern "C" void CASTER_NAME(caster_debug_wavelog_)(unsigned long long* out65536)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out65536, HIP_SYMBOL(g_caster_wavelog), sizeof(unsigned long long) * 65536);
 }
 #endif
 

@@ -20,10 +20,12 @@ struct ImgRec {
 };
 struct CamRec { float o[3], llc[3], h[3], v[3], u0[3], v0[3]; float lr; };
 
+constexpr int kMaxAlways = 4;
+
 struct SceneDev {
     const float4* sph;       // cx, cy, cz, r            (list order among spheres)
     const int2*   sph_meta;  // list position, material
-    const float4* sph_filter;// candidate filter: cx-Px, cy-Py, cz-Pz, C - r*r   (C = |c-P|^2; -inf = always a candidate)
+    const float4* sph_filter;// candidate filter: cx-Px, cy-Py, cz-Pz, C - r*r   (C = |c-P|^2; -inf = always a candidate, +inf = never: listed in `always`)
     const float*  sph_scale; // C + r*r, the scale of the filter's rounding error
     const float4* rect_a;    // cx, cy, cz, du
     const float4* rect_b;    // dv, 0, 0, 0
@@ -32,14 +34,19 @@ struct SceneDev {
     const ImgRec* imgs;
     int n_sph, n_rect, n_mat, n_img;
     float ref[3];            // P, the reference point of the candidate filter
+    int n_always;            // spheres tested directly for every ray, outside the filter
+    int always[kMaxAlways];  // their indices
 };
+
+constexpr int kMaxChunks = 256;
 
 struct RenderArgs {
     CamRec cam;
     SceneDev scene;
     int width, height;
     int s_begin, s_count;    // sample range of this call
-    int chunk, n_chunks;     // samples per work unit, units per pixel tile
+    int n_chunks;            // work units per pixel tile
+    int chunk_start[kMaxChunks + 1];   // chunk c covers samples s_begin + [chunk_start[c], chunk_start[c+1])
     int max_depth;
     uint32_t seed;
     unsigned long long* fixed; // width * height * 4 fixed-point sums (2^-32 units), zero at launch

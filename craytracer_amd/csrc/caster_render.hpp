@@ -39,7 +39,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWaves = kBlock / 64;
 constexpr int kSphTile = 512;               // spheres staged in LDS at a time (two 8 KiB images)
-constexpr int kMaxCand = 8;                 // deferred candidates per slot and lane before the list is worked off
+constexpr int kListCap = 16;                // candidate list entries per lane (u16 each) before the lists are worked off
 constexpr int kTileW = 8, kTileH = 8;       // pixels per work unit
 
 CDEV f2 splat(float x) { return f2{x, x}; }
@@ -104,8 +104,8 @@ struct Unit {
 
 constexpr int kAccStride = kTileW * kTileH * 3;     // one accumulator set: 64 pixels x RGB
 typedef unsigned long long acc_t;                   // fixed point, 32 fractional bits
-// LDS in front of the sphere images: accumulators, then the candidate lists
-constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * 2 * kAccStride + 2 * kWaves * 2 * kMaxCand * 64;
+// LDS in front of the sphere images: accumulators, candidate lists
+constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * 2 * kAccStride + 2 * kWaves * kListCap * 64;
 constexpr double kAccScale = 4294967296.0;
 
 // Pulls the next unit off the queue.  Units are numbered chunk-major.
@@ -125,9 +125,8 @@ CDEV Unit fetch_unit(const RenderArgs& a, int tiles_x, int n_tiles, int lane)
     un.tg.y0 = (tile / tiles_x) * kTileH;
     un.tg.tw = (a.width - un.tg.x0 < kTileW) ? a.width - un.tg.x0 : kTileW;
     un.tg.th = (a.height - un.tg.y0 < kTileH) ? a.height - un.tg.y0 : kTileH;
-    un.s0 = a.s_begin + chunk * a.chunk;
-    const int s_end = a.s_begin + a.s_count;
-    un.cs = (un.s0 + a.chunk < s_end) ? a.chunk : s_end - un.s0;
+    un.s0 = a.s_begin + a.chunk_start[chunk];
+    un.cs = a.chunk_start[chunk + 1] - a.chunk_start[chunk];
     un.total = (a.max_depth > 0) ? un.tg.tw * un.tg.th * un.cs : 0;
     return un;
 }
@@ -226,10 +225,11 @@ CDEV float4 exact_image(const float4 s /* cx, cy, cz, r */) { return make_float4
 // Pad entries: r*r = -1e30 gives a finite negative discriminant for every ray.
 CDEV float4 exact_pad() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
 CDEV float4 filter_pad() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
-// Host table entry {c'x, c'y, c'z, (C - r*r) | +inf for always, C + r*r in .w of a second table}: see filter_image.
-CDEV float4 filter_image(const float4 h /* c'x, c'y, c'z, K = C - r*r (or -inf) */, const float scale /* C + r*r */)
+// Host table entry {c'x, c'y, c'z, K = C - r*r}; K = -inf: always a candidate; K = +inf: never (the
+// sphere is tested directly, see test_always), stored like a pad entry.
+CDEV float4 filter_image(const float4 h, const float scale /* C + r*r */)
 {
-    return make_float4(h.x, h.y, kFilterMargin * scale - h.w, h.z);
+    return make_float4(h.x, h.y, (h.w == INFINITY) ? -1.0e30f : kFilterMargin * scale - h.w, h.z);
 }
 
 struct SphereLds {
@@ -238,9 +238,17 @@ struct SphereLds {
     int count;            // spheres in the tile, without the padding
 };
 
+// The filter works in coordinates relative to the reference point P (o' = o - P, c' = c - P) with
+// the unit direction u.  With w = o' - (o'.u)u, the part of o' perpendicular to the ray,
+//     discriminant / (d.d) = (c'.u)^2 + 2 c'.w - (|c'|^2 - r^2) - |w|^2 ,
+// so a sphere can only be hit if  (c'.u)^2 + (2w).c' - K  >=  |w|^2  (K = |c'|^2 - r^2 from the
+// table): seven packed operations per sphere and lane on the left, a number per ray on the right.
+// Rounding is covered by the margin g*(|o'|^2 + |c'|^2 + r^2): its sphere part is folded into the
+// table entry, its ray part into the threshold.
 struct PairRays {     // filter operands of both slots of a lane, packed
-    f2 p2x, p2y, p2z, ndx, ndy, ndz, od, base;
-    float force;      // +inf if either ray is not finite (every sphere is then a candidate), else -inf
+    f2 ux, uy, uz, p2x, p2y, p2z;
+    float thrA, thrB;           // a key below its slot's threshold: no hit possible
+    bool finiteA, finiteB;      // a ray with a non-finite component takes no part in the sphere loop (see non_finite_rule)
 };
 
 CDEV PairRays pack_rays(const Slot& sa, const Slot& sb, const float3 ref)
@@ -252,136 +260,136 @@ CDEV PairRays pack_rays(const Slot& sa, const Slot& sb, const float3 ref)
 #if CASTER_STRICT
     // the slots keep the reference's unnormalised direction; the filter wants a unit one
     const f2 inv = f2{__frsqrt_rn(sa.aa), __frsqrt_rn(sb.aa)};
-    const f2 ux = f2{sa.d.x, sb.d.x} * inv, uy = f2{sa.d.y, sb.d.y} * inv, uz = f2{sa.d.z, sb.d.z} * inv;
+    r.ux = f2{sa.d.x, sb.d.x} * inv; r.uy = f2{sa.d.y, sb.d.y} * inv; r.uz = f2{sa.d.z, sb.d.z} * inv;
 #else
-    const f2 ux = f2{sa.d.x, sb.d.x}, uy = f2{sa.d.y, sb.d.y}, uz = f2{sa.d.z, sb.d.z};
+    r.ux = f2{sa.d.x, sb.d.x}; r.uy = f2{sa.d.y, sb.d.y}; r.uz = f2{sa.d.z, sb.d.z};
 #endif
     const f2 oo = qx * qx + qy * qy + qz * qz;
-    r.od = qx * ux + qy * uy + qz * uz;
-    r.p2x = qx + qx; r.p2y = qy + qy; r.p2z = qz + qz;
-    r.ndx = -ux; r.ndy = -uy; r.ndz = -uz;
-    r.base = oo * splat(kFilterMargin - 1.0f);
-    // o'.o' and o'.u are finite exactly when every component of both rays is (overflow aside,
-    // which makes the ray a candidate everywhere: conservative)
-    const float probe = (oo.x + oo.y) + (r.od.x + r.od.y);
-    r.force = (probe - probe == 0.0f) ? -INFINITY : INFINITY;
+    const f2 od = qx * r.ux + qy * r.uy + qz * r.uz;
+    const f2 wx = qx - od * r.ux, wy = qy - od * r.uy, wz = qz - od * r.uz;
+    const f2 thr = (wx * wx + wy * wy + wz * wz) - oo * splat(kFilterMargin);
+    r.p2x = wx + wx; r.p2y = wy + wy; r.p2z = wz + wz;
+    r.thrA = thr.x; r.thrB = thr.y;
+    // the threshold is finite exactly when every component of the ray is (overflow aside, which
+    // makes the thresholds NaN or inf: the ray is then treated like a non-finite one)
+    r.finiteA = (thr.x - thr.x == 0.0f);
+    r.finiteB = (thr.y - thr.y == 0.0f);
     return r;
 }
 
-// Per sphere: the value whose sign decides whether the sphere is a candidate.
-CDEV f2 candidate_key(const PairRays& r, const float4 f)
+// Per sphere: the left-hand side of the candidate test.
+CDEV f2 candidate_key(const PairRays& r, const float4 f /* c'x, c'y, g*scale - K, c'z */)
 {
-    f2 hb = __builtin_elementwise_fma(r.ndz, splat(f.w), r.od);
-    hb = __builtin_elementwise_fma(r.ndy, splat(f.y), hb);
-    hb = __builtin_elementwise_fma(r.ndx, splat(f.x), hb);
-    f2 t2 = __builtin_elementwise_fma(r.p2z, splat(f.w), splat(f.z));
-    t2 = __builtin_elementwise_fma(r.p2y, splat(f.y), t2);
-    t2 = __builtin_elementwise_fma(r.p2x, splat(f.x), t2);
-    return __builtin_elementwise_fma(hb, hb, r.base) + t2;
+    f2 a = r.ux * splat(f.x);
+    a = __builtin_elementwise_fma(r.uy, splat(f.y), a);
+    a = __builtin_elementwise_fma(r.uz, splat(f.w), a);
+    f2 b = __builtin_elementwise_fma(r.p2x, splat(f.x), splat(f.z));
+    b = __builtin_elementwise_fma(r.p2y, splat(f.y), b);
+    b = __builtin_elementwise_fma(r.p2z, splat(f.w), b);
+    return __builtin_elementwise_fma(a, a, b);
 }
 
-CDEV bool is_candidate(float key)
+// The t at which the reference would report this sphere for this ray, if any, REGARDLESS of
+// the closest hit so far (src/caster.c:101-121): the first root if it is not below tmin, else
+// the second root if that is not below tmin.  The reference's in-order loop, which accepts a
+// sphere when that t does not exceed the closest t so far (an equal t replaces the earlier
+// sphere), ends with the smallest such t and, among equal ones, the latest sphere; a first
+// root beyond the closest hit is rejected there together with the second root, which is
+// never smaller.  So the closest hit is a minimum over (t, later-sphere-first) and can be taken
+// in any order.
+CDEV bool candidate_root(const float4 e /* cx, cy, r*r, cz */, V3 o, V3 d, float aa, float tmin, float& t)
 {
+    const float ocx = o.x - e.x, ocy = o.y - e.y, ocz = o.z - e.w;
 #if CASTER_STRICT
-    return !(key < 0.0f);       // a NaN key (non-finite ray) is a candidate: the reference lets NaN through (caster.c:107)
-#else
-    return key >= 0.0f;
-#endif
-}
-
-// Root selection and closest-hit update for one slot (src/caster.c:107-121, 209-214).
-CDEV void accept_one(const float4 e /* cx, cy, r*r, cz */, int index, const Slot& s, float& closest, int& best)
-{
-#if CASTER_STRICT
-    // The reference's arithmetic, operation for operation (src/caster.c:101-121), with two
-    // early returns that cannot change its outcome and spare most candidates the correctly
-    // rounded sqrt and divisions:
-    //  * hb >= 0 and c >= 0: then sqrt_d <= hb (sqrt(fl(hb*hb)) == hb exactly and the
-    //    discriminant is not larger), so both numerators are <= 0 and both roots fail
-    //    root < tmin (tmin > 0);
-    //  * -hb - sqrt_d > closest*a*(1 + 2^-21): then the correctly rounded quotient exceeds
-    //    closest, and so does the second root, whose numerator is not smaller.
-    const float ocx = s.o.x - e.x, ocy = s.o.y - e.y, ocz = s.o.z - e.w;
-    const float hb = (ocx * s.d.x + ocy * s.d.y) + ocz * s.d.z;
+    // The reference's arithmetic, operation for operation.  One early return that cannot change
+    // its outcome: hb >= 0 and c >= 0 give sqrt_d <= hb (sqrt(fl(hb*hb)) == hb exactly and the
+    // discriminant is not larger), so both numerators are <= 0 and both roots are below tmin > 0.
+    const float hb = (ocx * d.x + ocy * d.y) + ocz * d.z;
     const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - e.z;
-    const float disc = hb * hb - s.aa * c;
-    if (disc < 0.0f) return;
-    if (hb >= 0.0f && c >= 0.0f) return;
+    const float disc = hb * hb - aa * c;
+    if (disc < 0.0f) return false;
+    if (hb >= 0.0f && c >= 0.0f) return false;
     const float sq = sqrtf(disc);
-    const float num1 = -hb - sq;
-    if (num1 > (closest * s.aa) * 1.0000005f) return;
-    float root = num1 / s.aa;
-    if (root < s.tmin || root > closest) {
-        root = (-hb + sq) / s.aa;
-        if (root < s.tmin || root > closest) return;
+    float root = (-hb - sq) / aa;
+    if (root < tmin) {
+        root = (-hb + sq) / aa;
+        if (root < tmin) return false;
     }
-    closest = root;
-    best = index;
+    t = root;
+    return true;
 #else
-    // Explicit fmaf: this function is inlined once per slot, and a path must get the same
-    // bits in either slot, so the contraction pattern cannot be left to the compiler.
-    const float ocx = s.o.x - e.x, ocy = s.o.y - e.y, ocz = s.o.z - e.w;
-    const float hb = fmaf(ocz, s.d.z, fmaf(ocy, s.d.y, ocx * s.d.x));
+    (void)aa;   // the direction has unit length
+    const float hb = fmaf(ocz, d.z, fmaf(ocy, d.y, ocx * d.x));
     const float c = fmaf(ocz, ocz, fmaf(ocy, ocy, fmaf(ocx, ocx, -e.z)));
-    const float disc = fmaf(hb, hb, -c);                  // the direction has unit length
-    if (disc >= 0.0f && (hb < 0.0f || c < 0.0f)) {
-        const float sq = __builtin_amdgcn_sqrtf(disc);
-        float root = -hb - sq;
-        if (root < s.tmin || root > closest) root = -hb + sq;
-        if (!(root < s.tmin || root > closest)) { closest = root; best = index; }
-    }
+    const float disc = fmaf(hb, hb, -c);
+    if (!(disc >= 0.0f && (hb < 0.0f || c < 0.0f))) return false;
+    const float sq = __builtin_amdgcn_sqrtf(disc);
+    float root = -hb - sq;
+    if (root < tmin) root = -hb + sq;
+    if (root < tmin) return false;
+    t = root;
+    return true;
 #endif
 }
 
-// Candidates are not examined where they are found: a sphere is a candidate for a handful
-// of the wave's 128 rays at most, and the reference's root/closest-hit arithmetic (sqrt, two
-// divisions) would run for the whole wave each time.  Instead every lane appends the sphere's
-// tile position to a short list per slot (LDS, lane-minor), and the lists are worked off
-// together after the tile: trip i of that loop handles every lane's i-th candidate at once,
-// in list order, which is the reference's object order (src/caster.c:204-215).
-struct CandLists {
-    unsigned short* mem;    // [2 slots][kMaxCand][64 lanes], this wave's
-    int lane;
-    int cntA, cntB;         // entries of this lane
-};
-
-CDEV void push_candidate(CandLists& cl, int slot, int& cnt, int k)
+// Takes the hit at t on sphere `index` if it beats what the slot has: the reference's in-order
+// loop keeps the smallest t and, among equal ones, the latest sphere (src/caster.c:209-214).
+CDEV void take_hit(float t, int index, float& closest, int& best)
 {
-    cl.mem[(slot * kMaxCand + cnt) * 64 + cl.lane] = (unsigned short)k;
-    cnt++;
+    if (t < closest || (t == closest && index > best)) { closest = t; best = index; }
 }
+
+// Candidates are not examined where they are found: a sphere is a candidate for a handful of
+// the wave's 128 rays, and the root arithmetic (sqrt, divisions) would run for the whole wave
+// each time.  A lane that has a candidate in a group of kGroup spheres appends one 16-bit entry
+// to its own list in LDS -- group number and one bit per (sphere, slot) -- and the lists are
+// worked off after the tile, all lanes together, one candidate per lane and turn.
+struct CandLists {
+    unsigned short* mem;    // [kListCap][64], this wave's; entry i of a lane at mem[i * 64 + lane]
+    int cnt;                // entries in this lane's list
+#ifdef CASTER_TIMERS
+    unsigned long long ticks;
+#endif
+};
 
 CDEV void drain_candidates(CandLists& cl, const SphereLds& lds, int base, const Slot& sa, const Slot& sb,
                            float& closestA, float& closestB, int& bestA, int& bestB)
 {
-    for (int i = 0; __any((i < cl.cntA) | (i < cl.cntB)); ++i) {
+    CASTER_TIC(tq);
+    int cur = 0;
+    unsigned int bits = 0, group = 0;
+    for (;;) {
+        if (bits == 0 && cur < cl.cnt) {
+            const unsigned int e = cl.mem[cur * 64];
+            ++cur;
+            bits = e & 0xFFu;
+            group = e >> 8;
+        }
+        if (!__any(bits != 0)) break;
         CASTER_STAT(1);
-        if (i < cl.cntA) {
-            CASTER_STAT(2);
-            const int k = cl.mem[(0 * kMaxCand + i) * 64 + cl.lane];
-            accept_one(lds.exact[k], base + k, sa, closestA, bestA);
-        }
-        if (i < cl.cntB) {
-            CASTER_STAT(3);
-            const int k = cl.mem[(1 * kMaxCand + i) * 64 + cl.lane];
-            accept_one(lds.exact[k], base + k, sb, closestB, bestB);
+        if (bits != 0) {
+            // bit 7 - 2j - s stands for sphere j of the group and slot s
+            const int b = 31 - __clz((int)bits);
+            bits &= ~(1u << b);
+            const int j = 7 - b;
+            const int k = (int)group * kGroup + (j >> 1);
+            const bool second = (j & 1) != 0;
+            V3 o, d;
+            o.x = second ? sb.o.x : sa.o.x; o.y = second ? sb.o.y : sa.o.y; o.z = second ? sb.o.z : sa.o.z;
+            d.x = second ? sb.d.x : sa.d.x; d.y = second ? sb.d.y : sa.d.y; d.z = second ? sb.d.z : sa.d.z;
+            const float aa = second ? sb.aa : sa.aa;
+            const float tmin = second ? sb.tmin : sa.tmin;
+            float t;
+            if (candidate_root(lds.exact[k], o, d, aa, tmin, t)) {
+                if (second) take_hit(t, base + k, closestB, bestB);
+                else take_hit(t, base + k, closestA, bestA);
+            }
         }
     }
-    cl.cntA = 0;
-    cl.cntB = 0;
-}
-
-// Appends sphere k to the lists of the slots for which it is a candidate.
-CDEV void note_candidate(const f2 key, int k, CandLists& cl, const SphereLds& lds, int base,
-                         const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
-{
-    if (is_candidate(key.x) | is_candidate(key.y)) {
-        CASTER_STAT(12);
-        if (is_candidate(key.x)) { CASTER_STAT_LANES(13); push_candidate(cl, 0, cl.cntA, k); }
-        if (is_candidate(key.y)) { CASTER_STAT_LANES(13); push_candidate(cl, 1, cl.cntB, k); }
-        if (__any((cl.cntA >= kMaxCand) | (cl.cntB >= kMaxCand)))       // a list is full: work them off now
-            drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
-    }
+    cl.cnt = 0;
+#ifdef CASTER_TIMERS
+    CASTER_TOC(tq, cl.ticks);
+#endif
 }
 
 // A pipeline stage: kGroup spheres held in named registers (no indexed array,
@@ -398,49 +406,80 @@ CDEV Group load_group(const float4* src, int k)
     return g;
 }
 
+// Shifts the sign bit of x into m from the right.
+CDEV unsigned int push_sign(unsigned int m, float x) { return __builtin_amdgcn_alignbit(m, __float_as_uint(x), 31u); }
+
 // Evaluates the candidate keys of a group and looks at them together: a sphere is a candidate
 // for some ray of the wave only a few percent of the time, so one test of the group's largest
-// key (max3 chain) replaces two compares per sphere.  `force` is +inf for a lane whose ray is
-// not finite (its keys are NaN, which max3 would drop) and -inf otherwise.
-CDEV void process_group(const Group& g, int k, const PairRays& r, float force, CandLists& cl, const SphereLds& lds,
-                        int base, const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA,
-                        int& bestB)
+// key per slot (max3 chains) replaces two compares per sphere.  A non-finite ray has NaN
+// thresholds and is never a candidate.
+CDEV void process_group(const Group& g, int k, const PairRays& r, CandLists& cl, const SphereLds& lds, int base,
+                        const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
     const f2 k0 = candidate_key(r, g.g0);
     const f2 k1 = candidate_key(r, g.g1);
-    float m = __builtin_fmaxf(__builtin_fmaxf(k0.x, k0.y), force);
-    m = __builtin_fmaxf(__builtin_fmaxf(k1.x, k1.y), m);
     const f2 k2 = candidate_key(r, g.g2);
     const f2 k3 = candidate_key(r, g.g3);
-    m = __builtin_fmaxf(__builtin_fmaxf(k2.x, k2.y), m);
-    m = __builtin_fmaxf(__builtin_fmaxf(k3.x, k3.y), m);
-    if (m >= 0.0f) {
-        note_candidate(k0, k, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
-        note_candidate(k1, k + 1, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
-        note_candidate(k2, k + 2, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
-        note_candidate(k3, k + 3, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+    const float mA = __builtin_fmaxf(__builtin_fmaxf(k0.x, k1.x), __builtin_fmaxf(k2.x, k3.x));
+    const float mB = __builtin_fmaxf(__builtin_fmaxf(k0.y, k1.y), __builtin_fmaxf(k2.y, k3.y));
+    const bool mine = (mA >= r.thrA) | (mB >= r.thrB);
+    if (__any(mine)) {
+        CASTER_STAT(12);
+        if (__any(cl.cnt >= kListCap)) drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        // the sign bits of key - threshold, first key in bit 7; a clear bit is a candidate
+        unsigned int neg = push_sign(0u, k0.x - r.thrA);
+        neg = push_sign(neg, k0.y - r.thrB);
+        neg = push_sign(neg, k1.x - r.thrA);
+        neg = push_sign(neg, k1.y - r.thrB);
+        neg = push_sign(neg, k2.x - r.thrA);
+        neg = push_sign(neg, k2.y - r.thrB);
+        neg = push_sign(neg, k3.x - r.thrA);
+        neg = push_sign(neg, k3.y - r.thrB);
+        if (mine) {
+            cl.mem[cl.cnt * 64] = (unsigned short)(((unsigned int)(k / kGroup) << 8) | (~neg & 0xFFu));
+            ++cl.cnt;
+        }
     }
 }
 
 // Sphere loop over one LDS tile for the two slots of a lane.  cnt is a
 // multiple of 2*kGroup (the tile is padded) and kLdsSlack entries beyond it are
 // readable.  Two register sets alternate: while one group is evaluated the
-// next one is already on its way from LDS.  On return the candidate lists are
-// empty and closest / best hold what the reference's in-order loop would hold.
+// next one is already on its way from LDS.
 CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, CandLists& cl,
                      const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
     const float4* src = lds.filter;
-    const float force = r.force;
     Group ga = load_group(src, 0);
 #pragma unroll 1
     for (int k = 0; k < cnt; k += 2 * kGroup) {
         const Group gb = load_group(src, k + kGroup);
-        process_group(ga, k, r, force, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        process_group(ga, k, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
         ga = load_group(src, k + 2 * kGroup);
-        process_group(gb, k + kGroup, r, force, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        process_group(gb, k + kGroup, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
     }
     drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+}
+
+// The spheres that are candidates for every ray (SceneDev::n_always of them) do not go through
+// the lists: each lane tests them for its two slots directly.
+CDEV void test_always(const SceneView& sc, const Slot& sa, const Slot& sb, float& closestA, float& closestB,
+                      int& bestA, int& bestB)
+{
+    for (int h = 0; h < sc.n_always; ++h) {
+        const int index = sc.always[h];
+        const float4 e = exact_image(sc.sph[index]);
+        float t;
+        if (candidate_root(e, sa.o, sa.d, sa.aa, sa.tmin, t)) take_hit(t, index, closestA, bestA);
+        if (candidate_root(e, sb.o, sb.d, sb.aa, sb.tmin, t)) take_hit(t, index, closestB, bestB);
+    }
+}
+
+// A ray with a non-finite component makes every sphere test "accept" in the reference (NaN passes
+// the range checks, src/caster.c:107,114): it reports its last sphere with t = NaN.
+CDEV void non_finite_rule(bool finite, int n_sph, float& closest, int& best)
+{
+    if (!finite) { closest = __builtin_nanf(""); best = n_sph - 1; }
 }
 
 // Copies spheres [base, base+cnt) into LDS, padded to a multiple of 2*kGroup
@@ -528,10 +567,10 @@ __global__ __launch_bounds__(kBlock, 4)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    // layout: accumulators [kWaves][2][kAccStride] (acc_t), candidate lists [kWaves][2][kMaxCand][64]
-    // (u16), then the two sphere images
+    // layout: accumulators [kWaves][2][kAccStride] (acc_t), candidate lists [kWaves][kListCap][64] (u16),
+    // then the two sphere images
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
-    unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_dyn + sizeof(acc_t) * kWaves * 2 * kAccStride);
+    unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * 2 * kAccStride);
     float4* s_exact = reinterpret_cast<float4*>(s_dyn + kLdsFixedBytes);
     float4* s_filter = s_exact + a.lds_spheres;
 
@@ -566,9 +605,26 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     int bestA = -1, bestB = -1;
 
     CandLists cl;
-    cl.mem = s_cand + wave * 2 * kMaxCand * 64;
-    cl.lane = lane;
-    cl.cntA = cl.cntB = 0;
+    cl.mem = s_cand + wave * kListCap * 64 + lane;
+    cl.cnt = 0;
+#ifdef CASTER_TIMERS
+    cl.ticks = 0;
+#endif
+    CASTER_TIME_DECL(t_sched);
+    CASTER_TIME_DECL(t_bounce);
+    CASTER_TIME_DECL(t_refill);
+    CASTER_TIME_DECL(t_isect);
+    CASTER_TIME_DECL(t_total);
+    CASTER_TIME_DECL(n_trips);
+    CASTER_TIME_DECL(n_units_done);
+    CASTER_TIME_DECL(t_last_fetch);
+    CASTER_TIME_DECL(last_unit);
+    CASTER_TIME_DECL(t_empty);
+    CASTER_TIME_DECL(trips_at_empty);
+    CASTER_TIC(tt0);
+#ifdef CASTER_TIMERS
+    const unsigned long long wall0 = wall_clock64();     // 100 MHz
+#endif
 
     Unit cur, prev;                 // cur feeds the slots; prev only waits for its last paths
     cur.chunk = prev.chunk = -1;
@@ -580,6 +636,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     bool queue_empty = false;
 
     for (;;) {
+        CASTER_TIC(ts0);
         // retire the previous unit once its last path has ended
         if (prev.chunk >= 0) {
             const int pset = set ^ 1;
@@ -598,14 +655,24 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         if (cur.chunk < 0 && !queue_empty) {
             cur = fetch_unit(a, tiles_x, n_tiles, lane);
             queue_empty = cur.chunk < 0;
+#ifdef CASTER_TIMERS
+            n_units_done += queue_empty ? 0 : 1;
+            if (queue_empty) { t_empty = wall_clock64(); trips_at_empty = n_trips; }
+            else { t_last_fetch = wall_clock64(); last_unit = (unsigned long long)cur.chunk * 1000000ull + (cur.tg.y0 / 8) * 1000 + cur.tg.x0 / 8; }
+#endif
         }
+        CASTER_TOC(ts0, t_sched);
 
         // One copy of the per-slot code serves both slots (the slots trade places
         // after each turn), so a path computes the same values in either slot.
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {
+            CASTER_TIC(tb0);
             bounce(sa, closestA, bestA, sc, wave_acc, rays);
+            CASTER_TOC(tb0, t_bounce);
+            CASTER_TIC(tr0);
             refill(sa, cur, set, a, cam);
+            CASTER_TOC(tr0, t_refill);
             swap_slots(sa, sb);
             float tf = closestA; closestA = closestB; closestB = tf;
             int ti = bestA; bestA = bestB; bestB = ti;
@@ -626,9 +693,14 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         }
 
         CASTER_STAT(0);
-        closestA = sa.tmax; closestB = sb.tmax;
-        bestA = -1; bestB = -1;
+#ifdef CASTER_TIMERS
+        n_trips += 1;
+#endif
+        CASTER_TIC(ti0);
         const PairRays pr = pack_rays(sa, sb, ref);
+        closestA = sa.tmax; closestB = sb.tmax;     // a root equal to tmax is still accepted
+        bestA = bestB = -1;
+        test_always(sc, sa, sb, closestA, closestB, bestA, bestB);
         if (!TILED) {
             isect_tile(lds, n_lds, 0, pr, cl, sa, sb, closestA, closestB, bestA, bestB);
         } else {
@@ -641,8 +713,37 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
                 isect_tile(lds, padded, base, pr, cl, sa, sb, closestA, closestB, bestA, bestB);
             }
         }
+        non_finite_rule(pr.finiteA, sc.n_sph, closestA, bestA);
+        non_finite_rule(pr.finiteB, sc.n_sph, closestB, bestB);
+        CASTER_TOC(ti0, t_isect);
     }
+    CASTER_TOC(tt0, t_total);
+    CASTER_TIME_OUT(t_sched, 0);
+    CASTER_TIME_OUT(t_bounce, 1);
+    CASTER_TIME_OUT(t_refill, 2);
+    CASTER_TIME_OUT(t_isect, 3);
+    CASTER_TIME_OUT(t_total, 4);
+#ifdef CASTER_TIMERS
+    CASTER_TIME_OUT(cl.ticks, 5);
+    CASTER_TIME_OUT(wall_clock64() - wall0, 6);
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* wl = g_caster_wavelog + (blockIdx.x * 4 + wave) * 16;
+        wl[8] = t_bounce; wl[9] = t_refill; wl[10] = t_isect; wl[11] = cl.ticks; wl[12] = t_total; wl[13] = 0;
+        wl[0] = wall0; wl[1] = wall_clock64(); wl[2] = n_units_done; wl[3] = n_trips;
+        wl[4] = t_last_fetch; wl[5] = last_unit; wl[6] = t_empty; wl[7] = trips_at_empty;
+    }
+#ifndef CASTER_STATS
+    CASTER_TIME_OUT(n_trips, -16);
+#endif
+#endif
 
+#ifdef CASTER_TIMERS
+    {
+        unsigned int wr = rays;
+        for (int off = 32; off > 0; off >>= 1) wr += __shfl_down(wr, off, 64);
+        if (lane == 0 && blockIdx.x < 1024) g_caster_wavelog[(blockIdx.x * 4 + wave) * 16 + 13] = wr;
+    }
+#endif
     unsigned int wrays = rays;
     for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
     if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
@@ -683,7 +784,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
 {
     __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
     __shared__ float4 s_filter[kSphTile + 2 * kLdsSlack];
-    __shared__ unsigned short s_cand[kWaves * 2 * kMaxCand * 64];
+    __shared__ unsigned short s_cand[kWaves * kListCap * 64];
     const SceneView sc = view_of(sd);
     SphereLds lds;
     lds.exact = s_exact;
@@ -713,9 +814,12 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
     int best[2] = {-1, -1};
     const PairRays pr = pack_rays(sl[0], sl[1], ref);
     CandLists cl;
-    cl.mem = s_cand + (threadIdx.x >> 6) * 2 * kMaxCand * 64;
-    cl.lane = threadIdx.x & 63;
-    cl.cntA = cl.cntB = 0;
+    cl.mem = s_cand + (threadIdx.x >> 6) * kListCap * 64 + (threadIdx.x & 63);
+    cl.cnt = 0;
+#ifdef CASTER_TIMERS
+    cl.ticks = 0;
+#endif
+    test_always(sc, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
     for (int base = 0; base < sc.n_sph; base += kSphTile) {
         const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
         __syncthreads();
@@ -724,6 +828,8 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
         __syncthreads();
         isect_tile(lds, padded, base, pr, cl, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
     }
+    non_finite_rule(pr.finiteA, sc.n_sph, closest[0], best[0]);
+    non_finite_rule(pr.finiteB, sc.n_sph, closest[1], best[1]);
     for (int k = 0; k < 2; ++k) {
         if (i0 + k >= n) continue;
         const int i = i0 + k;
