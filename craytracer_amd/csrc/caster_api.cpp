@@ -360,11 +360,15 @@ int caster_hip_synchronize(caster_hip_ctx* ctx)
 }
 
 // Splits the sample range of a call into the chunks of the work units (unit = 8x8 pixel tile x chunk;
-// the queue hands the units out chunk by chunk).  Large chunks keep a wave's path slots full: a wave
-// moves on to its next unit while the last paths of the previous one finish, but holds only two units at a
-// time.  Smaller chunks at the end keep the waves from finishing far apart (a unit of 128 samples in a
-// costly part of the frame takes several percent of a 500-sample frame's time).  So: equal large
-// chunks first, then halves down to 16 samples.  The sums are integers, so the split does not change the result.
+// the queue hands the units out chunk by chunk).  A unit's sums are collected in LDS and reach the
+// frame buffer with one atomic per pixel and channel; paths that outlive their unit pay three
+// atomics each, so a chunk should hold many more paths than a wave has slots.  Against that, the
+// costliest tiles of a frame take many times the average (20 rays per path against 3 where two
+// spheres touch in the 1080p benchmark scene), and a unit that starts late and runs long leaves the
+// other waves idle at the end.  So every chunk is at most the share of the remaining samples that a
+// wave would still finish if its unit were 16 times the average: with many tiles per wave that is one
+// half, the chunks then halve towards the end.  The sums are integers, so the split does not change
+// the result.
 static int plan_chunks(const caster_hip_ctx* ctx, int width, int height, int sample_count, int* start)
 {
     const int cap = caster::kMaxChunks;
@@ -376,17 +380,17 @@ static int plan_chunks(const caster_hip_ctx* ctx, int width, int height, int sam
         for (int s = 0; s < sample_count; s += chunk) start[++n] = (s + chunk < sample_count) ? s + chunk : sample_count;
         return n;
     }
-    const long long tiles = (long long)((width + 7) / 8) * ((height + 7) / 8);
-    const long long waves = (long long)ctx->resident_blocks * 4;
-    long long bulk = (long long)sample_count * tiles / (16 * waves);     // >= 16 units per wave if the job allows it
-    if (bulk > 128) bulk = 128;
-    if (bulk < 8) bulk = 8;
-    if ((sample_count + bulk - 1) / bulk > cap - 16) bulk = (sample_count + cap - 17) / (cap - 16);
+    const double tiles = (double)((width + 7) / 8) * (double)((height + 7) / 8);
+    const double waves = (double)ctx->resident_blocks * 4.0;
+    double share = tiles / (16.0 * waves);
+    if (share > 0.5) share = 0.5;
+    int min_chunk = 4;
+    if (sample_count / min_chunk > cap - 32) min_chunk = (sample_count + cap - 33) / (cap - 32);
     int left = sample_count;
     while (left > 0) {
-        int c = (left + 1) / 2;
-        if (c > bulk) c = (int)bulk;
-        if (c < 16) c = 16;
+        int c = (int)((double)left * share);
+        if (c > 64 && min_chunk <= 64) c = 64;
+        if (c < min_chunk) c = min_chunk;
         if (c > left || n == cap - 1) c = left;
         start[n + 1] = start[n] + c;
         ++n;

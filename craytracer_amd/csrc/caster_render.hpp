@@ -51,7 +51,7 @@ struct Slot {
     float tmax;     // strict: 16777215 ; fast: 16777215 * |d|
     V3 thr;         // product of the attenuations so far
     Rng g;
-    int q;          // pixel of the tile this path belongs to (bits 0-5), accumulator set (bit 6)
+    int q;          // pixel this path belongs to: column in bits 0-15, row in bits 16-31
     int depth;      // rays this path may still shoot
     bool alive;
 };
@@ -105,7 +105,7 @@ struct Unit {
 constexpr int kAccStride = kTileW * kTileH * 3;     // one accumulator set: 64 pixels x RGB
 typedef unsigned long long acc_t;                   // fixed point, 32 fractional bits
 // LDS in front of the sphere images: accumulators, candidate lists
-constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * 2 * kAccStride + 2 * kWaves * kListCap * 64;
+constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * kAccStride + 2 * kWaves * kListCap * 64;
 constexpr double kAccScale = 4294967296.0;
 
 // Pulls the next unit off the queue.  Units are numbered chunk-major.
@@ -132,7 +132,7 @@ CDEV Unit fetch_unit(const RenderArgs& a, int tiles_x, int n_tiles, int lane)
 }
 
 // Camera ray for pool entry m of the unit: src/dispatcher.c:21-24.
-CDEV void start_pool_path(Slot& s, int m, const Unit& un, int set, const RenderArgs& a, const Cam& cam)
+CDEV void start_pool_path(Slot& s, int m, const Unit& un, const RenderArgs& a, const Cam& cam)
 {
     const int nvalid = un.tg.tw * un.tg.th;
     int smp, qx, qy;
@@ -151,25 +151,25 @@ CDEV void start_pool_path(Slot& s, int m, const Unit& un, int set, const RenderA
     const Ray r = ray_from_cam(cam, s.g, u, v);
     set_ray(s, r);
     s.thr = mk(1.0f, 1.0f, 1.0f);
-    s.q = (set << 6) | (qy * kTileW + qx);
+    s.q = (j << 16) | i;
     s.depth = a.max_depth;
     s.alive = true;
 }
 
 // Slots without a path take the next entries of the unit's pool, in lane order.
-CDEV void refill(Slot& s, Unit& un, int set, const RenderArgs& a, const Cam& cam)
+CDEV void refill(Slot& s, Unit& un, const RenderArgs& a, const Cam& cam)
 {
     if (un.chunk < 0 || un.next >= un.total) return;             // wave-uniform
     const unsigned long long want = __ballot(!s.alive);
     if (want == 0ull) return;
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
     const int m = un.next + rank;
-    if (!s.alive && m < un.total) { CASTER_STAT(11); start_pool_path(s, m, un, set, a, cam); }
+    if (!s.alive && m < un.total) { CASTER_STAT(11); start_pool_path(s, m, un, a, cam); }
     un.next += __popcll(want);
 }
 
-// Adds a finished unit's sums to the frame's fixed-point buffer (4 words per pixel: R, G, B,
-// unused) and clears the accumulator set.
+// Adds the sums of a unit's tile to the frame's fixed-point buffer (4 words per pixel: R, G, B,
+// unused) and clears the accumulator.
 CDEV void flush_unit(const Unit& un, acc_t* acc_set, const RenderArgs& a, int lane)
 {
     const int qx = lane & 7, qy = lane >> 3;
@@ -520,9 +520,30 @@ CDEV bool resolve_hit(const Slot& s, const Ray& r, float closest, int best_sph, 
     return true;
 }
 
+// A path has ended: its radiance goes to the accumulator of the wave's current tile in LDS if it
+// belongs to that tile, else (the wave has moved on to another unit meanwhile) straight to the
+// frame's fixed-point buffer.  Both are integer additions: the sum does not depend on the route.
+CDEV void deposit(int q, V3 radiance, const TileGeom& tg, acc_t* wave_acc, const RenderArgs& a)
+{
+    const int i = q & 0xFFFF, j = (int)((unsigned int)q >> 16);
+    const unsigned int qx = (unsigned int)(i - tg.x0), qy = (unsigned int)(j - tg.y0);
+    if (qx < (unsigned int)tg.tw && qy < (unsigned int)tg.th) {
+        acc_t* px = wave_acc + (qy * kTileW + qx) * 3;
+        if (radiance.x != 0.0f) atomicAdd(px + 0, to_fixed(radiance.x));
+        if (radiance.y != 0.0f) atomicAdd(px + 1, to_fixed(radiance.y));
+        if (radiance.z != 0.0f) atomicAdd(px + 2, to_fixed(radiance.z));
+    } else {
+        acc_t* px = a.fixed + 4 * ((size_t)j * a.width + i);
+        if (radiance.x != 0.0f) atomicAdd(px + 0, to_fixed(radiance.x));
+        if (radiance.y != 0.0f) atomicAdd(px + 1, to_fixed(radiance.y));
+        if (radiance.z != 0.0f) atomicAdd(px + 2, to_fixed(radiance.z));
+    }
+}
+
 // One bounce of a slot's path: shade the hit and either continue the path or
-// end it (adding its radiance to the tile).
-CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, acc_t* wave_acc, unsigned int& rays)
+// end it (adding its radiance to the frame).
+CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, const TileGeom& tg, acc_t* wave_acc,
+                 const RenderArgs& a, unsigned int& rays)
 {
     if (!s.alive) return;
     CASTER_STAT(6);
@@ -547,10 +568,7 @@ CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, acc_
         }
     }
     if (!cont) {
-        // s.q = set * 64 + pixel: the two sets are contiguous
-        if (radiance.x != 0.0f) atomicAdd(&wave_acc[s.q * 3 + 0], to_fixed(radiance.x));
-        if (radiance.y != 0.0f) atomicAdd(&wave_acc[s.q * 3 + 1], to_fixed(radiance.y));
-        if (radiance.z != 0.0f) atomicAdd(&wave_acc[s.q * 3 + 2], to_fixed(radiance.z));
+        deposit(s.q, radiance, tg, wave_acc, a);
         park(s);
     }
 }
@@ -567,10 +585,10 @@ __global__ __launch_bounds__(kBlock, 4)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
-    // layout: accumulators [kWaves][2][kAccStride] (acc_t), candidate lists [kWaves][kListCap][64] (u16),
+    // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists [kWaves][kListCap][64] (u16),
     // then the two sphere images
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
-    unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * 2 * kAccStride);
+    unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * kAccStride);
     float4* s_exact = reinterpret_cast<float4*>(s_dyn + kLdsFixedBytes);
     float4* s_filter = s_exact + a.lds_spheres;
 
@@ -582,8 +600,8 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     const int tiles_y = (a.height + kTileH - 1) / kTileH;
     const int n_tiles = tiles_x * tiles_y;
 
-    acc_t* wave_acc = s_acc + wave * 2 * kAccStride;
-    for (int k = lane; k < 2 * kAccStride; k += 64) wave_acc[k] = 0;
+    acc_t* wave_acc = s_acc + wave * kAccStride;
+    for (int k = lane; k < kAccStride; k += 64) wave_acc[k] = 0;
     int n_lds = 0;
     if (!TILED) n_lds = stage_spheres(s_exact, s_filter, sc, 0, sc.n_sph);
     SphereLds lds;
@@ -626,31 +644,24 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     const unsigned long long wall0 = wall_clock64();     // 100 MHz
 #endif
 
-    Unit cur, prev;                 // cur feeds the slots; prev only waits for its last paths
-    cur.chunk = prev.chunk = -1;
-    cur.next = cur.total = prev.next = prev.total = 0;
-    cur.cs = prev.cs = cur.s0 = prev.s0 = 0;
+    unsigned int trip = 0;
+    const unsigned int age = blockIdx.x * 4u / gridDim.x;       // blocks are placed in launch order, four per CU
+    // The unit that feeds the slots.  When its pool is empty its sums so far go to the frame buffer
+    // and the wave starts on the next unit at once; the paths still in flight then belong to a tile
+    // that is no longer the current one and deposit their radiance in the frame buffer themselves.
+    Unit cur;
+    cur.chunk = -1;
+    cur.next = cur.total = 0;
+    cur.cs = cur.s0 = 0;
     cur.tg.x0 = cur.tg.y0 = cur.tg.tw = cur.tg.th = 0;
-    prev.tg = cur.tg;
-    int set = 0;                    // accumulator set of cur; prev owns the other one
     bool queue_empty = false;
 
     for (;;) {
         CASTER_TIC(ts0);
-        // retire the previous unit once its last path has ended
-        if (prev.chunk >= 0) {
-            const int pset = set ^ 1;
-            const bool mine = (sa.alive && (sa.q >> 6) == pset) || (sb.alive && (sb.q >> 6) == pset);
-            if (!__any(mine ? 1 : 0)) {
-                flush_unit(prev, wave_acc + pset * kAccStride, a, lane);
-                prev.chunk = -1;
-            }
-        }
-        // the current unit's pool is empty: it becomes the one that waits, the wave moves on
-        if (cur.chunk >= 0 && cur.next >= cur.total && prev.chunk < 0) {
-            prev = cur;
+        if (cur.chunk >= 0 && cur.next >= cur.total) {
+            flush_unit(cur, wave_acc, a, lane);
             cur.chunk = -1;
-            set ^= 1;
+            cur.tg.tw = cur.tg.th = 0;      // no current tile
         }
         if (cur.chunk < 0 && !queue_empty) {
             cur = fetch_unit(a, tiles_x, n_tiles, lane);
@@ -668,10 +679,10 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {
             CASTER_TIC(tb0);
-            bounce(sa, closestA, bestA, sc, wave_acc, rays);
+            bounce(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
             CASTER_TOC(tb0, t_bounce);
             CASTER_TIC(tr0);
-            refill(sa, cur, set, a, cam);
+            refill(sa, cur, a, cam);
             CASTER_TOC(tr0, t_refill);
             swap_slots(sa, sb);
             float tf = closestA; closestA = closestB; closestB = tf;
@@ -679,7 +690,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         }
 
         const int live = (sa.alive || sb.alive) ? 1 : 0;
-        const bool done = queue_empty && cur.chunk < 0 && prev.chunk < 0;
+        const bool done = queue_empty && cur.chunk < 0;
         if (TILED) {
             // the tile loop below has block-wide barriers: all four waves leave together
             if (__syncthreads_or((live || !done) ? 1 : 0) == 0) break;
@@ -692,6 +703,15 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
             }
         }
 
+        // The SIMD issues from its oldest wave first, and these waves hardly ever stall: left alone,
+        // the youngest of the four waves on a SIMD runs several times slower than the oldest and
+        // its units finish last.  The issue priority goes round instead.
+        switch ((trip++ + age) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
         CASTER_STAT(0);
 #ifdef CASTER_TIMERS
         n_trips += 1;
