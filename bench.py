@@ -198,7 +198,7 @@ def main():
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(float(achieved) / FP32_VALU_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": recorded_traffic(f"rtiow_final_scene {W}x{H} {SPP}spp depth{args.depth}", args.mode, world),
                 "kernel": f"caster::render_kernel_{args.mode}<false>",
                 "flops_per_ray": flops_per_ray(ns, nr),
                 "note": "no dense contraction on this path: the bound is the FP32 vector (VALU) peak, not MFMA or HBM",
@@ -211,6 +211,21 @@ def main():
     gpu.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def recorded_traffic(workload, mode, world):
+    """HBM bytes per launch of the render kernel.  Counters cannot be read from inside a timed run:
+    the figure is the one measured with rocprofv3 --pmc passes for this exact workload, kept under
+    profiles/ together with how it was taken; None for any other workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if world == 1 and rec.get("workload") == workload and rec.get("arithmetic_mode") == mode:
+        return rec.get("bytes_per_launch")
+    return None
 
 
 if __name__ == "__main__":

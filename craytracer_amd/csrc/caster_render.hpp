@@ -10,23 +10,25 @@
 //   * every lane carries TWO path slots, so a wave traces 128 rays per loop
 //     trip and the sphere test runs on packed FP32 (v_pk_*_f32: slot A in the
 //     low half, slot B in the high half), one LDS broadcast read per sphere;
-//   * when a path ends, its radiance is added to the unit's accumulator in LDS
-//     and the slot takes the next (pixel, sample) of the unit's pool: the
-//     finished slots are found with a ballot and numbered with mbcnt, so the
-//     wave stays full.  When the pool runs dry the wave starts on its next
-//     unit while the last paths of the previous one are still in flight (two
-//     accumulator sets per wave); it never idles waiting for long paths;
-//   * the accumulators are 64-bit fixed point (2^-32 units): integer adds
-//     commute, so the sums do not depend on the order in which paths end and a
-//     render is bit-reproducible although the unit-to-wave assignment is not;
-//   * a finished unit's sums are added, still as integers, to a per-pixel
-//     fixed-point frame buffer in HBM (64-bit integer atomics: again order
-//     independent); a later kernel converts it to float once.
+//   * when a path ends, its radiance is added to the accumulator of the wave's
+//     current tile in LDS and the slot takes the next (pixel, sample) of the
+//     unit's pool: the finished slots are found with a ballot and numbered with
+//     mbcnt, so the wave stays full.  When the pool runs dry the tile's sums go
+//     to the frame buffer and the wave starts on its next unit at once; the
+//     paths of the old unit that are still in flight add their radiance to the
+//     frame buffer themselves when they end.  The wave never idles waiting for
+//     long paths;
+//   * all sums are 64-bit fixed point (2^-32 units): integer adds commute, so
+//     a pixel's sum does not depend on the order in which paths end, on the
+//     route their radiance takes or on the unit-to-wave assignment, and a
+//     render is bit-reproducible;
+//   * the frame buffer is a per-pixel fixed-point buffer in HBM (64-bit
+//     integer atomics); a later kernel converts it to float once.
 //
 // Every ray is tested against every sphere (src/caster.c:204 has no early
 // out): the loop evaluates a conservative candidate test for both slots
-// branch-free and enters the root/closest-hit code only when some lane has a
-// candidate.
+// branch-free, notes the few candidates in per-lane lists and runs the
+// reference's root arithmetic on those after the loop.
 #pragma once
 
 #include "caster_device.hpp"
@@ -202,17 +204,15 @@ CDEV acc_t to_fixed(float x)
 //
 // Every ray meets every sphere (the reference has no early out), but only a
 // few spheres per ray can be hit.  The loop therefore evaluates, for both slots
-// of the lane at once, a conservative candidate test and runs the reference's
-// own arithmetic only for the candidates.  With unit direction u, o' = o-P and
-// c' = c-P the discriminant of src/caster.c:105 has the sign of
-//   hb*hb - |o-c|^2 + r*r = (hb*hb - |o'|^2) + (2 o'.c' - (C - r*r)),  hb = o'.u - c'.u,
-// which needs no per-sphere subtraction: 8 packed FP32 instructions per sphere
-// and lane pair.  The key adds a margin g*(|o'|^2 + C + r*r) that exceeds the
-// rounding error of both this form and the reference's form, so a sphere the
-// reference's test would accept is always a candidate; what the candidate code
-// then decides is exactly what the reference decides (strict mode) or the same
-// test on the unit direction (fast mode).  Spheres much larger than the rest
-// (ground, sky) carry +inf and are always candidates.
+// of the lane at once, a conservative candidate test (see PairRays: 7 packed
+// FP32 instructions per sphere and lane pair) and runs the reference's own
+// arithmetic only for the candidates.  The test carries a margin
+// g*(|o'|^2 + C + r*r) that exceeds the rounding error of both its own form and
+// the reference's form, so a sphere the reference's test would accept is
+// always a candidate; what the candidate code then decides is exactly what the
+// reference decides (strict mode) or the same test on the unit direction (fast
+// mode).  Spheres much larger than the rest (ground, sky) are candidates for
+// every ray and are tested directly (test_always).
 constexpr int kGroup = 4;               // spheres per software-pipeline stage
 #if CASTER_STRICT
 constexpr float kFilterMargin = 1.0e-5f;
