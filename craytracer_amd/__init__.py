@@ -27,7 +27,10 @@ from .binding import (  # noqa: F401
     load_caster_lib,
     load_host_lib,
     scene_0,
+    scene_perlin,
     scene_rtiow,
+    make_noise,
+    NOISE_DTYPE,
     scene_stress,
     make_test_texture,
     bmp_encode,

@@ -26,6 +26,8 @@ MATERIAL_DTYPE = np.dtype(
         ("pad", "<i4"),
     ]
 )
+NOISE_DTYPE = np.dtype([("ranvec", "<f4", (256, 3)), ("perm_x", "u1", (256,)), ("perm_y", "u1", (256,)),
+                        ("perm_z", "u1", (256,))])      # caster_noise
 assert OBJECT_DTYPE.itemsize == 32 and MATERIAL_DTYPE.itemsize == 48
 
 
@@ -73,7 +75,8 @@ def load_host_lib():
             raise CasterHipError(f"{path} is missing: build it with `make -C craytracer_amd/host`")
         lib = C.CDLL(path)
         for name in ("crt_scene_0", "crt_scene_rtiow", "crt_scene_stress", "crt_flatten", "crt_make_test_texture",
-                     "new_image_buffer", "crt_flat_objects", "crt_flat_materials", "crt_flat_images"):
+                     "new_image_buffer", "crt_flat_objects", "crt_flat_materials", "crt_flat_images",
+                     "crt_flat_noise", "crt_scene_perlin", "new_noise_perlin"):
             getattr(lib, name).restype = C.c_void_p
         lib.crt_bmp_encode.restype = C.c_long
         _host = lib
@@ -108,6 +111,7 @@ class FlatScene:
     objects: np.ndarray                      # OBJECT_DTYPE, list order
     materials: np.ndarray                    # MATERIAL_DTYPE
     images: List[np.ndarray] = field(default_factory=list)   # uint8 [h, w, bpp]
+    noise: Optional[np.ndarray] = None       # NOISE_DTYPE, the tables the TTYPE_NOISE materials share
 
     @property
     def n_spheres(self) -> int:
@@ -134,6 +138,7 @@ class _Scene(C.Structure):
         ("rects", C.c_void_p), ("n_rects", C.c_int32),
         ("materials", C.c_void_p), ("n_materials", C.c_int32),
         ("texture_image", C.c_void_p),
+        ("noise", C.c_void_p),
     ]
 
 
@@ -160,7 +165,11 @@ def _flatten_scene_ptr(scene_ptr) -> FlatScene:
                 im = arr[k]
                 raw = C.string_at(im.data, im.w * im.h * im.bpp)
                 images.append(np.frombuffer(raw, dtype=np.uint8).reshape(im.h, im.w, im.bpp).copy())
-        return FlatScene(objs, mats, images)
+        noise = None
+        pn = host.crt_flat_noise(C.c_void_p(fs))
+        if pn:
+            noise = np.frombuffer(C.string_at(pn, NOISE_DTYPE.itemsize), dtype=NOISE_DTYPE).copy().reshape(())
+        return FlatScene(objs, mats, images, noise)
     finally:
         host.crt_flat_free(C.c_void_p(fs))
 
@@ -192,6 +201,26 @@ def scene_rtiow(seed: int = 1) -> FlatScene:
         return _flatten_scene_ptr(p)
     finally:
         host.crt_scene_free(C.c_void_p(p))
+
+
+def scene_perlin(seed: int = 1) -> FlatScene:
+    """The RTIOW layout with marble (Perlin noise) textures on the ground and the diffuse spheres."""
+    host = load_host_lib()
+    p = host.crt_scene_perlin(C.c_uint32(seed))
+    try:
+        return _flatten_scene_ptr(p)
+    finally:
+        host.crt_scene_free(C.c_void_p(p))
+
+
+def make_noise(seed: int = 1) -> np.ndarray:
+    """new_noise_perlin(seed) as a NOISE_DTYPE record."""
+    host = load_host_lib()
+    p = host.new_noise_perlin(C.c_uint32(seed))
+    try:
+        return np.frombuffer(C.string_at(p, NOISE_DTYPE.itemsize), dtype=NOISE_DTYPE).copy().reshape(())
+    finally:
+        host.free_noise_perlin(C.c_void_p(p))
 
 
 def scene_stress(n: int, seed: int = 2) -> FlatScene:
@@ -285,6 +314,9 @@ class CasterHip:
             ),
             "caster_hip_upload_scene",
         )
+        if fs.noise is not None:
+            noise = np.ascontiguousarray(fs.noise, dtype=NOISE_DTYPE).reshape(1)
+            _check(self._lib.caster_hip_set_noise(self._ctx, _ptr(noise)), "caster_hip_set_noise")
 
     # -- device memory
     def malloc(self, nbytes: int) -> int:

@@ -43,6 +43,7 @@ struct caster_hip_ctx {
     bool has_scene = false;
     caster::SceneDev scene{};
     std::vector<void*> scene_allocs;
+    bool needs_noise = false;   // the scene has a CASTER_TTYPE_NOISE material
     // scratch
     unsigned long long* fixed = nullptr;      // per-pixel fixed-point sums of the call in flight
     size_t fixed_bytes = 0;
@@ -75,6 +76,7 @@ void free_scene(caster_hip_ctx* ctx)
     ctx->scene_allocs.clear();
     ctx->scene = caster::SceneDev{};
     ctx->has_scene = false;
+    ctx->needs_noise = false;
 }
 
 template <typename T>
@@ -227,6 +229,8 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
         const caster_material& m = materials[k];
         if (m.type < 0 || m.type > CASTER_MTYPE_DIFF_LIGHT)
             return fail(CASTER_HIP_ERR_ARG, "material %d: unknown type tag %d", k, m.type);
+        if (m.tex_type < 0 || m.tex_type > CASTER_TTYPE_NOISE)
+            return fail(CASTER_HIP_ERR_ARG, "material %d: unknown texture tag %d", k, m.tex_type);
         if (m.tex_type == CASTER_TTYPE_IMAGE_ALBEDO && (m.image < 0 || m.image >= n_images))
             return fail(CASTER_HIP_ERR_ARG, "material %d: image %d out of range [0, %d)", k, m.image, n_images);
     }
@@ -306,6 +310,29 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
     s.n_mat = n_materials;
     s.n_img = n_images;
     ctx->has_scene = true;
+    for (int k = 0; k < n_materials; ++k)
+        if (materials[k].tex_type == CASTER_TTYPE_NOISE) ctx->needs_noise = true;
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_set_noise(caster_hip_ctx* ctx, const caster_noise* noise)
+{
+    if (!ctx || !noise) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "caster_hip_set_noise before caster_hip_upload_scene");
+    for (int k = 0; k < 256; ++k)
+        for (int c = 0; c < 3; ++c)
+            if (!std::isfinite(noise->ranvec[k][c])) return fail(CASTER_HIP_ERR_ARG, "noise vector %d is not finite", k);
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::vector<float4> vec(256);
+    for (int k = 0; k < 256; ++k) vec[k] = make_float4(noise->ranvec[k][0], noise->ranvec[k][1], noise->ranvec[k][2], 0.0f);
+    std::vector<uint8_t> perm(768);
+    memcpy(perm.data(), noise->perm_x, 256);
+    memcpy(perm.data() + 256, noise->perm_y, 256);
+    memcpy(perm.data() + 512, noise->perm_z, 256);
+    int rc;
+    if ((rc = upload_array(ctx, vec, &ctx->scene.noise_vec))) return rc;
+    if ((rc = upload_array(ctx, perm, &ctx->scene.noise_perm))) return rc;
     return CASTER_HIP_OK;
 }
 
@@ -405,6 +432,8 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
 {
     if (!ctx || !cam || !accum_dev) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
     if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "render before caster_hip_upload_scene");
+    if (ctx->needs_noise && !ctx->scene.noise_vec)
+        return fail(CASTER_HIP_ERR_STATE, "the scene has a noise texture: call caster_hip_set_noise first");
     if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
         return fail(CASTER_HIP_ERR_ARG, "frame size %dx%d out of range", width, height);
     if (sample_begin < 0 || sample_count < 0) return fail(CASTER_HIP_ERR_ARG, "negative sample range");

@@ -84,6 +84,8 @@ struct SceneView {
     int n_sph, n_rect, n_mat, n_img;
     int n_always;
     int always[4];          // spheres tested directly for every ray
+    const float4* noise_vec;    // Perlin tables (in LDS inside the render kernel), or null
+    const uint8_t* noise_perm;
 };
 
 CDEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -370,6 +372,56 @@ CDEV float clampf(float x, float lo, float hi)                  // common.c:25-2
     return x;
 }
 
+// Gradient noise and turbulence for TTYPE_NOISE.  No counterpart in the reference (inc/noise.h:4-7
+// is a placeholder, src/noise.c is empty): the published construction of "Ray Tracing: The Next
+// Week".  Eight lattice corners around p each hold a unit vector chosen by xor-ing three
+// permutation tables; the value interpolates dot(vector, offset from the corner) with
+// Hermite-smoothed weights.
+CDEV float noise_value(const SceneView& sc, V3 p)
+{
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const float uu = u * u * (3.0f - 2.0f * u);
+    const float vv = v * v * (3.0f - 2.0f * v);
+    const float ww = w * w * (3.0f - 2.0f * w);
+    const uint8_t* px = sc.noise_perm;
+    const uint8_t* py = px + 256;
+    const uint8_t* pz = px + 512;
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; di++) {
+        const unsigned int hx = px[(i + di) & 255];
+        const float wi = di ? uu : 1.0f - uu;
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++) {
+            const unsigned int hxy = hx ^ py[(j + dj) & 255];
+            const float wj = dj ? vv : 1.0f - vv;
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                const float4 c = sc.noise_vec[hxy ^ pz[(k + dk) & 255]];
+                const float wk = dk ? ww : 1.0f - ww;
+                const float ox = u - (float)di, oy = v - (float)dj, oz = w - (float)dk;
+                const float d = (c.x * ox + c.y * oy) + c.z * oz;
+                accum += ((wi * wj) * wk) * d;
+            }
+        }
+    }
+    return accum;
+}
+
+CDEV float noise_turb(const SceneView& sc, V3 p)
+{
+    float accum = 0.0f, weight = 1.0f;
+    V3 temp = p;
+    for (int k = 0; k < 7; k++) {
+        accum += weight * noise_value(sc, temp);
+        weight *= 0.5f;
+        temp = temp * 2.0f;
+    }
+    return fabsf(accum);
+}
+
 CDEV V3 texture_color(const SceneView& sc, const Mat& m, HitRec& rec)           // material.c:65-101
 {
     switch (m.tex) {
@@ -393,6 +445,11 @@ CDEV V3 texture_color(const SceneView& sc, const Mat& m, HitRec& rec)           
         const float color_scale = 1.0f / 255.0f;
         const uint8_t* pix = im.data + (size_t)j * im.w * im.bpp + (size_t)i * im.bpp;
         return mk(color_scale * (float)pix[0], color_scale * (float)pix[1], color_scale * (float)pix[2]);
+    }
+    case 4: { // TTYPE_NOISE (extension): marble
+        if (!sc.noise_vec) return mk(0.0f, 0.0f, 0.0f);
+        const float s = 0.5f * (1.0f + m_sin(m.c1[0] * rec.p.z + 10.0f * noise_turb(sc, rec.p)));
+        return mk(m.c0[0] * s, m.c0[1] * s, m.c0[2] * s);
     }
     default:
         return mk(0.0f, 0.0f, 0.0f);

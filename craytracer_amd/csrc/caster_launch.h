@@ -34,6 +34,8 @@ struct SceneDev {
     const ImgRec* imgs;
     int n_sph, n_rect, n_mat, n_img;
     float ref[3];            // P, the reference point of the candidate filter
+    const float4* noise_vec; // 256 unit vectors (w unused), or null
+    const uint8_t* noise_perm; // perm_x[256], perm_y[256], perm_z[256], or null
     int n_always;            // spheres tested directly for every ray, outside the filter
     int always[kMaxAlways];  // their indices
 };

@@ -51,11 +51,22 @@ img_buffer* read_bitmap_image(const char* filename);
 
 /* inc/material.h:8-35 */
 #define TEXTURE_COLOR_UNITS 8
-typedef struct texture { v3_f32 color[TEXTURE_COLOR_UNITS]; u8 type; img_buffer* image; } texture;
+/* inc/noise.h:4-7 declares the placeholder `noise_perlin { int todo; }` and src/noise.c is empty.
+ * Here the type holds the tables of gradient ("Perlin") noise as "Ray Tracing: The Next Week"
+ * builds them: 256 random unit vectors and three permutations of 0..255. */
+typedef struct noise_perlin { v3_f32 ranvec[256]; u8 perm_x[256], perm_y[256], perm_z[256]; } noise_perlin;
+noise_perlin* new_noise_perlin(u32 seed);
+void free_noise_perlin(noise_perlin* noise);
+
+/* `noise` is an extension of the reference's struct (last field): the tables of a TTYPE_NOISE
+ * texture, whose colour is color[0] * 0.5 * (1 + sin(color[1].x * p.z + 10 * turbulence(p))).
+ * All noise textures of a scene share one table. */
+typedef struct texture { v3_f32 color[TEXTURE_COLOR_UNITS]; u8 type; img_buffer* image; noise_perlin* noise; } texture;
 #define TTYPE_COLOR 0
 #define TTYPE_CHECKER 1
 #define TTYPE_IMAGE_ALBEDO 2
 #define TTYPE_IMAGE_EMIT 3
+#define TTYPE_NOISE 4
 typedef struct material { i8 type; texture texture; f32 fuzziness; f32 n_refract; } material;
 #define MTYPE_LAMBERTIAN 0
 #define MTYPE_METAL 1
@@ -126,6 +137,7 @@ typedef struct {
     xy_rect* rects; i32 n_rects;
     material* materials; i32 n_materials;
     img_buffer* texture_image;   /* owned, may be NULL */
+    noise_perlin* noise;         /* owned, may be NULL */
 } crt_scene;
 
 /* src/main.c:14-55: ground checker sphere, glass sphere, image-textured sphere,
@@ -135,6 +147,9 @@ crt_scene* crt_scene_0(img_buffer* earth);
 /* RTIOW final scene built from the reference's primitives, lit by an enclosing
  * emissive sphere (the reference returns black on a miss, src/caster.c:482). */
 crt_scene* crt_scene_rtiow(u32 scene_seed);
+/* The same layout with marble (TTYPE_NOISE) textures on the ground, the diffuse small spheres
+ * and the big diffuse sphere. */
+crt_scene* crt_scene_perlin(u32 scene_seed);
 /* n small spheres scattered over the ground plus ground and sky spheres. */
 crt_scene* crt_scene_stress(i32 n, u32 scene_seed);
 void crt_scene_free(crt_scene* sc);
@@ -152,6 +167,7 @@ int crt_flat_counts(const crt_flat_scene* fs, int* n_objects, int* n_materials, 
 const void* crt_flat_objects(const crt_flat_scene* fs);    /* caster_object[]   */
 const void* crt_flat_materials(const crt_flat_scene* fs);  /* caster_material[] */
 const void* crt_flat_images(const crt_flat_scene* fs);     /* caster_image[]    */
+const void* crt_flat_noise(const crt_flat_scene* fs);      /* caster_noise* or NULL */
 
 /* Bytes write_img_buffer_to_file() writes, into out (54 + h*stride bytes). */
 long crt_bmp_encode(const img_buffer* buffer, u8* out);

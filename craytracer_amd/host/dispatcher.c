@@ -68,6 +68,8 @@ static void* job_main(void* arg)
         (rc = caster_hip_upload_scene(job->ctx, n_obj, (const caster_object*)crt_flat_objects(be->flat), n_mat,
                                       (const caster_material*)crt_flat_materials(be->flat), n_img,
                                       (const caster_image*)crt_flat_images(be->flat))) ||
+        (crt_flat_noise(be->flat) &&
+         (rc = caster_hip_set_noise(job->ctx, (const caster_noise*)crt_flat_noise(be->flat)))) ||
         (rc = caster_hip_malloc(job->ctx, accum_bytes, (void**)&job->accum_dev)) ||
         (rc = caster_hip_memset_zero(job->ctx, job->accum_dev, accum_bytes))) {
         job_fail(job, rc);

@@ -13,7 +13,12 @@ struct crt_flat_scene {
     caster_image* images; int n_images;
     const material** mat_keys;
     const img_buffer** img_keys;
+    const noise_perlin* noise;      /* the table the scene's noise textures share, or NULL */
+    int noise_conflict;             /* two noise textures with different tables */
 };
+
+/* noise_perlin is handed to libcaster_hip as it is */
+_Static_assert(sizeof(noise_perlin) == sizeof(caster_noise), "noise table layout");
 
 static int find_or_add_image(crt_flat_scene* fs, const img_buffer* img)
 {
@@ -40,6 +45,10 @@ static int find_or_add_material(crt_flat_scene* fs, const material* m)
     for (int c = 0; c < 3; c++) { o->color0[c] = m->texture.color[0].p[c]; o->color1[c] = m->texture.color[1].p[c]; }
     o->fuzziness = m->fuzziness;
     o->n_refract = m->n_refract;
+    if (m->texture.type == TTYPE_NOISE) {
+        if (!m->texture.noise || (fs->noise && fs->noise != m->texture.noise)) fs->noise_conflict = 1;
+        fs->noise = m->texture.noise;
+    }
     o->image = (m->texture.type == TTYPE_IMAGE_ALBEDO || m->texture.type == TTYPE_IMAGE_EMIT)
                    ? find_or_add_image(fs, m->texture.image) : -1;
     return k;
@@ -77,6 +86,10 @@ crt_flat_scene* crt_flatten(const hit_list* world)
         }
         fs->n_objects++;
     }
+    if (fs->noise_conflict) {       /* a noise texture without a table, or two different tables */
+        crt_flat_free(fs);
+        return NULL;
+    }
     return fs;
 }
 
@@ -99,3 +112,4 @@ int crt_flat_counts(const crt_flat_scene* fs, int* n_objects, int* n_materials, 
 const void* crt_flat_objects(const crt_flat_scene* fs) { return fs ? fs->objects : NULL; }
 const void* crt_flat_materials(const crt_flat_scene* fs) { return fs ? fs->materials : NULL; }
 const void* crt_flat_images(const crt_flat_scene* fs) { return fs ? fs->images : NULL; }
+const void* crt_flat_noise(const crt_flat_scene* fs) { return fs ? fs->noise : NULL; }

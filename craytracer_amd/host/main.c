@@ -2,7 +2,7 @@
  * arguments -- height, samples per pixel, max depth, "threads" (here: GPUs) --
  * same camera, same output file; the preview window is left out.
  *
- *   craytracer <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|stress:N]
+ *   craytracer <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|perlin|stress:N]
  *              [--seed S] [--strict] [--batch B] [--texture file.bmp] [--out file.bmp]
  */
 #include "craytracer.h"
@@ -13,7 +13,7 @@
 int main(int argc, char* argv[])
 {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|stress:N] [--seed S] "
+        fprintf(stderr, "usage: %s <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|perlin|stress:N] [--seed S] "
                         "[--strict] [--batch B] [--texture file.bmp] [--out file.bmp]\n", argv[0]);
         return 2;
     }
@@ -56,6 +56,8 @@ int main(int argc, char* argv[])
         scene = crt_scene_0(earth);
     } else if (!strcmp(scene_name, "rtiow")) {
         scene = crt_scene_rtiow(1);
+    } else if (!strcmp(scene_name, "perlin")) {
+        scene = crt_scene_perlin(1);
     } else if (!strncmp(scene_name, "stress:", 7)) {
         scene = crt_scene_stress(atoi(scene_name + 7), 2);
     }

@@ -6,6 +6,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 hit_list new_hit_list(void)                                  /* src/caster.c:169-176 */
 {
@@ -72,6 +73,7 @@ void crt_scene_free(crt_scene* sc)
     free(sc->rects);
     free(sc->materials);
     free_image_buffer(sc->texture_image);
+    free_noise_perlin(sc->noise);
     free(sc);
 }
 
@@ -164,6 +166,86 @@ crt_scene* crt_scene_rtiow(u32 scene_seed)
     }
     add_sphere(sc, 0.0f, 1.0f, 0.0f, 1.0f, add_material(sc, MTYPE_DIELECTRIC, TTYPE_COLOR, 0, 0, 0, 0.0f, 1.5f));
     add_sphere(sc, -4.0f, 1.0f, 0.0f, 1.0f, add_material(sc, MTYPE_LAMBERTIAN, TTYPE_COLOR, 0.4f, 0.2f, 0.1f, 0.0f, 0.0f));
+    add_sphere(sc, 4.0f, 1.0f, 0.0f, 1.0f, add_material(sc, MTYPE_METAL, TTYPE_COLOR, 0.7f, 0.6f, 0.5f, 0.0f, 0.0f));
+    add_sphere(sc, 0.0f, 0.0f, 0.0f, 100000.0f, add_material(sc, MTYPE_DIFF_LIGHT, TTYPE_COLOR, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f));
+    return sc;
+}
+
+/* Gradient-noise tables: 256 unit vectors with components drawn from [-1, 1) and three
+ * Fisher-Yates permutations of 0..255 (the construction of "Ray Tracing: The Next Week"; the
+ * reference's inc/noise.h:4-7 is a placeholder). */
+noise_perlin* new_noise_perlin(u32 seed)
+{
+    noise_perlin* n = (noise_perlin*)calloc(1, sizeof *n);
+    if (!n) return NULL;
+    scene_rng g;
+    srng_init(&g, seed ^ 0x50455231u);
+    for (int k = 0; k < 256; k++) {
+        f32 x, y, z, len2;
+        do {
+            x = srnd_range(&g, -1.0f, 1.0f); y = srnd_range(&g, -1.0f, 1.0f); z = srnd_range(&g, -1.0f, 1.0f);
+            len2 = x * x + y * y + z * z;
+        } while (len2 < 1.0e-6f);
+        const f32 len = sqrtf(len2);
+        n->ranvec[k].x = x / len; n->ranvec[k].y = y / len; n->ranvec[k].z = z / len;
+    }
+    u8* perms[3] = {n->perm_x, n->perm_y, n->perm_z};
+    for (int t = 0; t < 3; t++) {
+        u8* p = perms[t];
+        for (int k = 0; k < 256; k++) p[k] = (u8)k;
+        for (int k = 255; k > 0; k--) {
+            int target = (int)(srnd(&g) * (f32)(k + 1));
+            if (target > k) target = k;
+            const u8 tmp = p[k]; p[k] = p[target]; p[target] = tmp;
+        }
+    }
+    return n;
+}
+
+void free_noise_perlin(noise_perlin* noise) { free(noise); }
+
+static material* add_noise_material(crt_scene* sc, i8 type, f32 r, f32 g, f32 b, f32 scale, f32 fuzz)
+{
+    material* m = add_material(sc, type, TTYPE_NOISE, r, g, b, fuzz, 0.0f);
+    m->texture.color[1].x = scale;
+    m->texture.noise = sc->noise;
+    return m;
+}
+
+/* The layout of crt_scene_rtiow with marble textures: ground, diffuse small spheres and the
+ * big diffuse sphere are TTYPE_NOISE, the metals keep a solid colour. */
+crt_scene* crt_scene_perlin(u32 scene_seed)
+{
+    crt_scene* sc = scene_alloc(22 * 22 + 5, 0, 22 * 22 + 5);
+    if (!sc) return NULL;
+    sc->noise = new_noise_perlin(scene_seed);
+    if (!sc->noise) { crt_scene_free(sc); return NULL; }
+    scene_rng g;
+    srng_init(&g, scene_seed);
+    add_sphere(sc, 0.0f, -1000.0f, 0.0f, 1000.0f, add_noise_material(sc, MTYPE_LAMBERTIAN, 1.0f, 1.0f, 1.0f, 4.0f, 0.0f));
+    for (int a = -11; a < 11; a++) {
+        for (int b = -11; b < 11; b++) {
+            const f32 choose = srnd(&g);
+            const f32 cx = (f32)a + 0.9f * srnd(&g);
+            const f32 cz = (f32)b + 0.9f * srnd(&g);
+            const f32 dx = cx - 4.0f, dz = cz;
+            if (dx * dx + dz * dz <= 0.9f * 0.9f) continue;
+            material* m;
+            if (choose < 0.8f) {
+                const f32 r = srnd_range(&g, 0.3f, 1.0f), gg = srnd_range(&g, 0.3f, 1.0f), bb = srnd_range(&g, 0.3f, 1.0f);
+                m = add_noise_material(sc, MTYPE_LAMBERTIAN, r, gg, bb, srnd_range(&g, 4.0f, 40.0f), 0.0f);
+            } else if (choose < 0.95f) {
+                const f32 r = srnd_range(&g, 0.5f, 1.0f), gg = srnd_range(&g, 0.5f, 1.0f), bb = srnd_range(&g, 0.5f, 1.0f);
+                const f32 fuzz = srnd_range(&g, 0.0f, 0.5f);
+                m = add_material(sc, MTYPE_METAL, TTYPE_COLOR, r, gg, bb, fuzz, 0.0f);
+            } else {
+                m = add_material(sc, MTYPE_DIELECTRIC, TTYPE_COLOR, 0.0f, 0.0f, 0.0f, 0.0f, 1.5f);
+            }
+            add_sphere(sc, cx, 0.2f, cz, 0.2f, m);
+        }
+    }
+    add_sphere(sc, 0.0f, 1.0f, 0.0f, 1.0f, add_material(sc, MTYPE_DIELECTRIC, TTYPE_COLOR, 0, 0, 0, 0.0f, 1.5f));
+    add_sphere(sc, -4.0f, 1.0f, 0.0f, 1.0f, add_noise_material(sc, MTYPE_LAMBERTIAN, 1.0f, 0.9f, 0.8f, 8.0f, 0.0f));
     add_sphere(sc, 4.0f, 1.0f, 0.0f, 1.0f, add_material(sc, MTYPE_METAL, TTYPE_COLOR, 0.7f, 0.6f, 0.5f, 0.0f, 0.0f));
     add_sphere(sc, 0.0f, 0.0f, 0.0f, 100000.0f, add_material(sc, MTYPE_DIFF_LIGHT, TTYPE_COLOR, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f));
     return sc;

@@ -44,7 +44,8 @@ enum {
 /* Object, material and texture tags: inc/caster.h:71-75, inc/material.h:17-20,32-35. */
 enum { CASTER_HTYPE_SPHERE = 0, CASTER_HTYPE_RECT_XY = 1 };
 enum { CASTER_MTYPE_LAMBERTIAN = 0, CASTER_MTYPE_METAL = 1, CASTER_MTYPE_DIELECTRIC = 2, CASTER_MTYPE_DIFF_LIGHT = 3 };
-enum { CASTER_TTYPE_COLOR = 0, CASTER_TTYPE_CHECKER = 1, CASTER_TTYPE_IMAGE_ALBEDO = 2, CASTER_TTYPE_IMAGE_EMIT = 3 };
+enum { CASTER_TTYPE_COLOR = 0, CASTER_TTYPE_CHECKER = 1, CASTER_TTYPE_IMAGE_ALBEDO = 2, CASTER_TTYPE_IMAGE_EMIT = 3,
+       CASTER_TTYPE_NOISE = 4 /* extension: see caster_noise */ };
 
 /* One hit_list entry (inc/caster.h:39-55,64-69) with pointers flattened.
  * sphere: g = {cx, cy, cz, radius, -, -};  xy rect: g = {cx, cy, cz, du, dv, -}.
@@ -72,6 +73,16 @@ typedef struct {
     const uint8_t* data;
     uint32_t w, h, bpp;
 } caster_image;
+
+/* Perlin noise tables for CASTER_TTYPE_NOISE materials (color0 = colour, color1[0] = scale):
+ * colour * 0.5 * (1 + sin(scale * p.z + 10 * turbulence(p))), 7 octaves of gradient noise over
+ * 256 unit vectors chosen through three xor-ed permutation tables.  The reference only declares
+ * a placeholder (inc/noise.h:4-7, src/noise.c is empty): there is nothing in it to match, the
+ * construction is the published one of "Ray Tracing: The Next Week". */
+typedef struct {
+    float ranvec[256][3];
+    uint8_t perm_x[256], perm_y[256], perm_z[256];
+} caster_noise;
 
 /* inc/camera.h:6-13 (cam_info): 19 floats, same order. */
 typedef struct {
@@ -101,6 +112,11 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx,
                             int n_objects, const caster_object* objects,
                             int n_materials, const caster_material* materials,
                             int n_images, const caster_image* images);
+
+/* The noise tables of the scene uploaded last (inc/noise.h:4-7 is the reference's placeholder for
+ * them).  Required before rendering a scene that has a CASTER_TTYPE_NOISE material;
+ * caster_hip_upload_scene forgets them. */
+int caster_hip_set_noise(caster_hip_ctx* ctx, const caster_noise* noise);
 
 /* Device memory helpers for hosts that do not manage HIP memory themselves. */
 int caster_hip_malloc(caster_hip_ctx* ctx, size_t bytes, void** dev_ptr);

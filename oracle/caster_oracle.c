@@ -340,6 +340,42 @@ int orc_scatter_dielectric(const oscene* sc, orng* g, const oray* r, const ohit*
 }
 
 /* src/material.c:58-101 */
+/* Gradient noise at p (extension, see onoise in the header): the eight lattice corners around p
+ * each hold a unit vector chosen by xor-ing three permutation tables; the result interpolates
+ * dot(vector, offset from the corner) with Hermite-smoothed weights.  Zero at lattice points. */
+float orc_noise_value(const onoise* n, ov3 p)
+{
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float uu = u * u * (3 - 2 * u);
+    float vv = v * v * (3 - 2 * v);
+    float ww = w * w * (3 - 2 * w);
+    float accum = 0.0f;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                const float* c = n->ranvec[n->perm_x[(i + di) & 255] ^ n->perm_y[(j + dj) & 255] ^ n->perm_z[(k + dk) & 255]];
+                float wx = u - di, wy = v - dj, wz = w - dk;
+                float d = c[0] * wx + c[1] * wy + c[2] * wz;
+                accum += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) * d;
+            }
+    return accum;
+}
+
+float orc_noise_turb(const onoise* n, ov3 p, int depth)
+{
+    float accum = 0.0f;
+    ov3 temp = p;
+    float weight = 1.0f;
+    for (int k = 0; k < depth; k++) {
+        accum += weight * orc_noise_value(n, temp);
+        weight *= 0.5f;
+        temp = v3_smul(temp, 2.0f);
+    }
+    return fabsf(accum);
+}
+
 ov3 orc_texture_get_color_at(const oscene* sc, const omat* m, ov2 uv, ov3 p)
 {
     switch (m->tex_type) {
@@ -362,6 +398,10 @@ ov3 orc_texture_get_color_at(const oscene* sc, const omat* m, ov2 uv, ov3 p)
         const float color_scale = 1.0f / 255.0f;
         const uint8_t* pix = img->data + j * img->w * img->bpp + i * img->bpp;
         return v3(color_scale * pix[0], color_scale * pix[1], color_scale * pix[2]);
+    }
+    case ORC_TTYPE_NOISE: {     /* extension, see onoise in the header */
+        float s = 0.5f * (1.0f + sinf(m->color1[0] * p.z + 10 * orc_noise_turb(sc->noise, p, 7)));
+        return v3(m->color0[0] * s, m->color0[1] * s, m->color0[2] * s);
     }
     }
     /* The reference falls off the end of the function here (undefined value);

@@ -42,7 +42,8 @@ typedef struct {
 /* Object / material / texture tags: inc/caster.h:71-75, inc/material.h:17-20,32-35 */
 enum { ORC_HTYPE_SPHERE = 0, ORC_HTYPE_RECT_XY = 1 };
 enum { ORC_MTYPE_LAMBERTIAN = 0, ORC_MTYPE_METAL = 1, ORC_MTYPE_DIELECTRIC = 2, ORC_MTYPE_DIFF_LIGHT = 3 };
-enum { ORC_TTYPE_COLOR = 0, ORC_TTYPE_CHECKER = 1, ORC_TTYPE_IMAGE_ALBEDO = 2, ORC_TTYPE_IMAGE_EMIT = 3 };
+enum { ORC_TTYPE_COLOR = 0, ORC_TTYPE_CHECKER = 1, ORC_TTYPE_IMAGE_ALBEDO = 2, ORC_TTYPE_IMAGE_EMIT = 3,
+       ORC_TTYPE_NOISE = 4 /* extension, see onoise */ };
 
 /* inc/material.h:10-30 flattened: two colour units are all the path reads. */
 typedef struct {
@@ -69,6 +70,17 @@ typedef struct {        /* inc/image.h:6-12 */
     uint32_t w, h, bpp;
 } oimage;
 
+/* Perlin noise tables.  EXTENSION WITHOUT A REFERENCE COUNTERPART: the reference declares
+ * `noise_perlin { int todo; }` (inc/noise.h:4-7) and src/noise.c is empty.  What is restated here
+ * is the published gradient-noise construction of "Ray Tracing: The Next Week" (256 random unit
+ * vectors, three permutation tables, Hermite-smoothed trilinear interpolation, 7-octave
+ * turbulence, marble texture colour * 0.5 * (1 + sin(scale * p.z + 10 * turb(p)))).  A noise
+ * texture is a material with tex_type ORC_TTYPE_NOISE, color0 = colour, color1[0] = scale. */
+typedef struct {
+    float ranvec[256][3];
+    uint8_t perm_x[256], perm_y[256], perm_z[256];
+} onoise;               /* 3840 bytes */
+
 typedef struct {
     int32_t count;
     int32_t nmats;
@@ -77,6 +89,7 @@ typedef struct {
     const oobj* objs;
     const omat* mats;
     const oimage* images;
+    const onoise* noise;    /* NULL unless a material uses ORC_TTYPE_NOISE */
 } oscene;
 
 typedef struct {        /* inc/camera.h:6-13 */
@@ -120,6 +133,8 @@ int  orc_scatter_metal(const oscene* sc, orng* g, const oray* r, const ohit* rec
 int  orc_scatter_dielectric(const oscene* sc, orng* g, const oray* r, const ohit* rec, oray* out);
 ov2  orc_get_uv_coord_sphere(ov3 p);
 ov3  orc_texture_get_color_at(const oscene* sc, const omat* m, ov2 uv, ov3 p);
+float orc_noise_value(const onoise* n, ov3 p);
+float orc_noise_turb(const onoise* n, ov3 p, int depth);
 ov3  orc_ray_color(const oscene* sc, orng* g, const oray* r, int depth, int64_t* total_rays);
 
 ocam orc_calculate_cam_info(ov3 pos, ov3 look_at, ov3 up, float fov, float ar, float aperture, float focus);

@@ -20,6 +20,8 @@ MAT_DTYPE = np.dtype(
     [("type", "<i4"), ("tex_type", "<i4"), ("color0", "<f4", (3,)), ("color1", "<f4", (3,)),
      ("fuzziness", "<f4"), ("n_refract", "<f4"), ("image", "<i4"), ("pad", "<i4")]
 )
+NOISE_DTYPE = np.dtype([("ranvec", "<f4", (256, 3)), ("perm_x", "u1", (256,)), ("perm_y", "u1", (256,)),
+                        ("perm_z", "u1", (256,))])
 RNG_COUNTER, RNG_LIBC = 0, 1
 
 
@@ -29,7 +31,7 @@ class _OImage(C.Structure):
 
 class _OScene(C.Structure):
     _fields_ = [("count", C.c_int32), ("nmats", C.c_int32), ("nimages", C.c_int32), ("pad", C.c_int32),
-                ("objs", C.c_void_p), ("mats", C.c_void_p), ("images", C.c_void_p)]
+                ("objs", C.c_void_p), ("mats", C.c_void_p), ("images", C.c_void_p), ("noise", C.c_void_p)]
 
 
 class _OV3(C.Structure):
@@ -76,19 +78,21 @@ def _f32(a, shape=None):
 class Scene:
     """Holds numpy copies of the flat tables and the C struct that points at them."""
 
-    def __init__(self, objects, materials, images=()):
+    def __init__(self, objects, materials, images=(), noise=None):
         self.objects = np.ascontiguousarray(objects, dtype=OBJ_DTYPE)
         self.materials = np.ascontiguousarray(materials, dtype=MAT_DTYPE)
         self.images = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
         self._imgs = (_OImage * max(1, len(self.images)))()
         for k, im in enumerate(self.images):
             self._imgs[k] = _OImage(im.ctypes.data, im.shape[1], im.shape[0], im.shape[2])
+        self.noise = None if noise is None else np.ascontiguousarray(noise, dtype=NOISE_DTYPE).reshape(1)
         self.c = _OScene(len(self.objects), len(self.materials), len(self.images), 0,
-                         self.objects.ctypes.data, self.materials.ctypes.data, C.addressof(self._imgs))
+                         self.objects.ctypes.data, self.materials.ctypes.data, C.addressof(self._imgs),
+                         None if self.noise is None else self.noise.ctypes.data)
 
     @classmethod
     def from_flat(cls, fs):
-        return cls(fs.objects, fs.materials, fs.images)
+        return cls(fs.objects, fs.materials, fs.images, getattr(fs, "noise", None))
 
 
 def calculate_cam_info(pos, look_at, up, fov, aspect, aperture, focus) -> np.ndarray:
@@ -190,6 +194,23 @@ def texture(scene: Scene, mat, uv2, p3):
     rgb = np.zeros((n, 3), np.float32)
     lib().orc_batch_texture(C.byref(scene.c), C.c_int(n), _p(mat), _p(uv2), _p(p3), _p(rgb))
     return rgb
+
+
+def noise_value(noise, p3):
+    """orc_noise_value for an array of points (pure-Python loop over a C call: small inputs only)."""
+    noise = np.ascontiguousarray(noise, dtype=NOISE_DTYPE).reshape(1)
+    f = lib().orc_noise_value
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, _OV3]
+    return np.array([f(noise.ctypes.data, _OV3(*map(float, p))) for p in _f32(p3, (-1, 3))], dtype=np.float32)
+
+
+def noise_turb(noise, p3, depth=7):
+    noise = np.ascontiguousarray(noise, dtype=NOISE_DTYPE).reshape(1)
+    f = lib().orc_noise_turb
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p, _OV3, C.c_int]
+    return np.array([f(noise.ctypes.data, _OV3(*map(float, p)), depth) for p in _f32(p3, (-1, 3))], dtype=np.float32)
 
 
 def rng(seed, pixel, sample, n):

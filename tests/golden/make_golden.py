@@ -26,6 +26,7 @@ IMAGE_CASES = {
     "scene_0": (lambda: ca.scene_0(), 64, 36, 16, 50, 0xC0FFEE),
     "scene_0_textured": (lambda: ca.scene_0(textured=True), 48, 27, 8, 50, 17),
     "rtiow": (lambda: ca.scene_rtiow(1), 48, 27, 4, 50, 3),
+    "perlin": (lambda: ca.scene_perlin(1), 48, 27, 4, 50, 7),
 }
 
 
@@ -67,6 +68,10 @@ def main():
     vec["schlick_cos"] = cosv
     vec["schlick_15"] = np.array([orc.reflectance(c, 1.5) for c in cosv], np.float32)
     vec["schlick_inv15"] = np.array([orc.reflectance(c, np.float32(1.0) / np.float32(1.5)) for c in cosv], np.float32)
+    noise = ca.make_noise(1)
+    pts = rng.uniform(-30, 30, (256, 3)).astype(np.float32)
+    vec.update(noise_tables=np.frombuffer(noise.tobytes(), np.uint8), noise_points=pts,
+               noise_value=orc.noise_value(noise, pts), noise_turb=orc.noise_turb(noise, pts))
     np.savez_compressed(os.path.join(OUT, "vectors.npz"), **vec)
     print("wrote", os.path.join(OUT, "images.npz"), os.path.join(OUT, "vectors.npz"))
 

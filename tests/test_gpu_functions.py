@@ -210,6 +210,38 @@ def test_texture_parity(gpu, orc, ca):
     assert (np.all(g[chk] == o[chk], axis=1)).mean() > 0.9995
 
 
+def test_noise_texture_parity(gpu, orc, ca):
+    """The marble texture (Perlin noise; an extension, the reference only holds a placeholder for it):
+    the noise arithmetic is bit-exact against the CPU restatement, the final sine is evaluated in double
+    and rounded, so values agree to the last place or two."""
+    rng = np.random.default_rng(108)
+    fs = ca.scene_perlin(1)
+    gpu.upload_scene(fs)
+    sc = orc.Scene.from_flat(fs)
+    n = 20000
+    noisy = np.flatnonzero(fs.materials["tex_type"] == 4)
+    mat = rng.choice(noisy, size=n).astype(np.int32)
+    p = rng.uniform(-30, 30, size=(n, 3)).astype(np.float32)
+    p[:8] = [[0, 0, 0], [1, 2, 3], [-1, -2, -3], [0.5, 0.5, 0.5], [255.5, -255.5, 256], [1e-6, -1e-6, 0], [1000, -1000, 4], [3.999999, 4, 4.000001]]
+    uv = np.zeros((n, 2), np.float32)
+    g = gpu.test_texture(mat, uv, p, strict=True)
+    o = orc.texture(sc, mat, uv, p)
+    assert np.isfinite(g).all() and g.min() >= 0.0 and g.max() <= 1.0
+    assert (g == o).all(axis=1).mean() > 0.98
+    assert np.abs(g - o).max() < 3e-7
+    f = gpu.test_texture(mat, uv, p, strict=False)
+    assert np.abs(f - o).max() < 2e-4
+    # without tables the scene cannot be rendered: a loud error, not black pixels
+    bare = ca.FlatScene(fs.objects, fs.materials, fs.images, None)
+    gpu.upload_scene(bare)
+    acc = gpu.malloc(16 * 16 * 16)
+    try:
+        with pytest.raises(ca.CasterHipError, match="noise"):
+            gpu.render(ca.default_camera(1.0), 16, 16, 0, 1, 5, 1, acc, strict=True)
+    finally:
+        gpu.free(acc)
+
+
 def test_fast_mode_functions_close(gpu, orc, ca):
     """The fast arithmetic mode (FMA allowed) stays within a few ULP on well-conditioned inputs."""
     rng = np.random.default_rng(107)
@@ -307,6 +339,7 @@ def test_golden_images(gpu, ca):
 
     images = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "images.npz"))
     makers = {"scene_0": lambda: ca.scene_0(), "scene_0_textured": lambda: ca.scene_0(textured=True),
+              "perlin": lambda: ca.scene_perlin(1),
               "rtiow": lambda: ca.scene_rtiow(1)}
     for name, make in makers.items():
         w, h, spp, depth, seed = (int(v) for v in images[name + "_cfg"])

@@ -16,7 +16,8 @@ def _bmp_pixels(data, w, h):
     return body.reshape(h, w, 3)
 
 
-@pytest.mark.parametrize("scene,make", [("0", lambda ca: ca.scene_0(textured=True)), ("rtiow", lambda ca: ca.scene_rtiow(1))])
+@pytest.mark.parametrize("scene,make", [("0", lambda ca: ca.scene_0(textured=True)), ("rtiow", lambda ca: ca.scene_rtiow(1)),
+                                        ("perlin", lambda ca: ca.scene_perlin(1))])
 def test_cli_output_matches_restatement(tmp_path, ca, orc, scene, make):
     exe = os.path.join(os.path.dirname(ca.lib_paths()["host"]), "craytracer")
     out = str(tmp_path / "output.bmp")

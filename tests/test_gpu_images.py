@@ -29,6 +29,7 @@ SCENES = {
     "scene_0_textured": dict(make=lambda ca: ca.scene_0(textured=True), w=80, h=45, spp=16, depth=50, seed=11),
     "rtiow": dict(make=lambda ca: ca.scene_rtiow(1), w=64, h=36, spp=8, depth=50, seed=3),
     "rtiow_depth3": dict(make=lambda ca: ca.scene_rtiow(1), w=48, h=27, spp=8, depth=3, seed=4),
+    "perlin": dict(make=lambda ca: ca.scene_perlin(1), w=64, h=36, spp=6, depth=50, seed=6),
     "stress_1500": dict(make=lambda ca: ca.scene_stress(1500, 2), w=40, h=24, spp=4, depth=50, seed=5),
 }
 

@@ -100,6 +100,25 @@ def test_rtiow_and_stress_scenes(ca):
     assert r.min() >= 0.1 and r.max() <= 0.5
 
 
+def test_perlin_scene_and_noise_tables(ca):
+    n1, n2, n3 = ca.make_noise(1), ca.make_noise(1), ca.make_noise(2)
+    assert n1.tobytes() == n2.tobytes() and n1.tobytes() != n3.tobytes()
+    assert np.allclose(np.linalg.norm(n1["ranvec"], axis=1), 1.0, atol=1e-6)
+    for t in ("perm_x", "perm_y", "perm_z"):
+        assert sorted(n1[t].tolist()) == list(range(256))                 # a permutation of 0..255
+    assert n1["perm_x"].tolist() != n1["perm_y"].tolist()
+    fs = ca.scene_perlin(1)
+    assert fs.noise is not None and fs.noise.tobytes() == ca.make_noise(1).tobytes()
+    rt = ca.scene_rtiow(1)
+    assert abs(len(fs.objects) - len(rt.objects)) < 8 and np.array_equal(fs.objects["g"][-4:], rt.objects["g"][-4:])
+    assert np.array_equal(fs.objects["g"][0], rt.objects["g"][0])
+    tex = fs.materials["tex_type"][fs.objects["material"]]
+    assert tex[0] == 4 and (tex == 4).sum() > 300 and tex[-1] == 0
+    noisy = fs.materials[fs.materials["tex_type"] == 4]
+    assert (noisy["type"] == 0).all() and noisy["color1"][:, 0].min() >= 4.0 and noisy["color1"][:, 0].max() <= 40.0
+    assert ca.scene_rtiow(1).noise is None
+
+
 def test_host_camera_equals_oracle_camera(ca, orc):
     for aspect in (16 / 9, 4 / 3, 1.0):
         assert np.array_equal(ca.default_camera(aspect), orc.default_camera(aspect))

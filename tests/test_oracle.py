@@ -154,7 +154,7 @@ def test_camera_golden_and_thin_lens_property(orc, vectors):
 
 def test_images_golden(orc, ca, images):
     makers = {"scene_0": lambda: ca.scene_0(), "scene_0_textured": lambda: ca.scene_0(textured=True),
-              "rtiow": lambda: ca.scene_rtiow(1)}
+              "rtiow": lambda: ca.scene_rtiow(1), "perlin": lambda: ca.scene_perlin(1)}
     for name, make in makers.items():
         w, h, spp, depth, seed = (int(v) for v in images[name + "_cfg"])
         sums, rays = orc.render(orc.Scene.from_flat(make()), ca.default_camera(w / h), w, h, spp, depth, seed)
@@ -223,3 +223,49 @@ def test_libc_rand_mode_agrees_statistically(orc, ca):
     diff = np.mean((enc(a) - enc(c)) ** 2)
     assert diff < 1.6 * noise
     assert abs(enc(a).mean() - enc(c).mean()) < 0.01
+
+
+def test_noise_properties(orc, ca, vectors):
+    """Gradient noise (an extension: the reference's inc/noise.h is a placeholder, nothing to pin it to)
+    against what the construction guarantees: zero on the lattice, period 256, continuity, and a
+    float64 restatement of the same formula."""
+    noise = ca.make_noise(1)
+    assert noise.tobytes() == vectors["noise_tables"].tobytes()
+    assert np.array_equal(orc.noise_value(noise, vectors["noise_points"]), vectors["noise_value"])
+    assert np.array_equal(orc.noise_turb(noise, vectors["noise_points"]), vectors["noise_turb"])
+    rng = np.random.default_rng(5)
+    lattice = rng.integers(-300, 300, size=(200, 3)).astype(np.float32)
+    assert np.all(orc.noise_value(noise, lattice) == 0.0)
+    p = rng.uniform(-40, 40, size=(400, 3)).astype(np.float32)
+    v = orc.noise_value(noise, p)
+    assert np.abs(v).max() < 1.0 and v.std() > 0.1
+    assert np.allclose(orc.noise_value(noise, p + np.float32(256.0)), v, atol=2e-4)        # the tables wrap at 256
+    assert np.abs(orc.noise_value(noise, p + np.float32(1e-3)) - v).max() < 1e-2           # continuous
+
+    def ref64(q):
+        q = q.astype(np.float64)
+        f = np.floor(q)
+        u, v_, w = (q - f)
+        i, j, k = f.astype(int)
+        uu, vv, ww = u * u * (3 - 2 * u), v_ * v_ * (3 - 2 * v_), w * w * (3 - 2 * w)
+        acc = 0.0
+        for di in (0, 1):
+            for dj in (0, 1):
+                for dk in (0, 1):
+                    c = noise["ranvec"][int(noise["perm_x"][(i + di) & 255]) ^ int(noise["perm_y"][(j + dj) & 255])
+                                        ^ int(noise["perm_z"][(k + dk) & 255])].astype(np.float64)
+                    acc += ((di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww))
+                            * np.dot(c, [u - di, v_ - dj, w - dk]))
+        return acc
+
+    assert np.allclose(v[:60], [ref64(q) for q in p[:60]], atol=5e-6)
+    t = orc.noise_turb(noise, p[:100])
+    assert np.all(t >= 0) and t.max() < 2.0
+    # the marble texture: colour * 0.5 * (1 + sin(scale * z + 10 * turb))
+    fs = ca.scene_perlin(1)
+    sc = orc.Scene.from_flat(fs)
+    m = int(np.flatnonzero(fs.materials["tex_type"] == 4)[0])
+    rgb = orc.texture(sc, np.full(100, m, np.int32), np.zeros((100, 2), np.float32), p[:100])
+    t_scene = orc.noise_turb(fs.noise, p[:100])
+    want = 0.5 * (1 + np.sin(fs.materials["color1"][m, 0].astype(np.float64) * p[:100, 2] + 10.0 * t_scene.astype(np.float64)))
+    assert np.allclose(rgb, fs.materials["color0"][m][None, :] * want[:, None], atol=1e-5)

@@ -23,6 +23,8 @@ args = ap.parse_args()
 
 if args.scene == "rtiow":
     fs = ca.scene_rtiow(1)
+elif args.scene == "perlin":
+    fs = ca.scene_perlin(1)
 elif args.scene == "scene_0":
     fs = ca.scene_0()
 elif args.scene.startswith("stress:"):
