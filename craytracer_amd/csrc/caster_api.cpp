@@ -298,6 +298,15 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
     if ((rc = upload_array(ctx, sph, &s.sph))) return rc;
     if ((rc = upload_array(ctx, sph_filter, &s.sph_filter))) return rc;
     if ((rc = upload_array(ctx, sph_scale, &s.sph_scale))) return rc;
+    for (int mode = 0; mode < 2; ++mode) {
+        const float margin = mode ? caster::kFilterMarginStrict : caster::kFilterMarginFast;
+        std::vector<float4> img(sph.size() + 16, make_float4(0.0f, 0.0f, -1.0e30f, 0.0f));
+        for (size_t k = 0; k < sph.size(); ++k) {
+            const float4 h = sph_filter[k];
+            img[k] = make_float4(h.x, h.y, (h.w == INFINITY) ? -1.0e30f : margin * sph_scale[k] - h.w, h.z);
+        }
+        if ((rc = upload_array(ctx, img, &s.filter_img[mode]))) return rc;
+    }
     s.ref[0] = (float)ref[0]; s.ref[1] = (float)ref[1]; s.ref[2] = (float)ref[2];
     if ((rc = upload_array(ctx, sph_meta, &s.sph_meta))) return rc;
     if ((rc = upload_array(ctx, rect_a, &s.rect_a))) return rc;

@@ -76,6 +76,7 @@ struct SceneView {
     const int2*   sph_meta; // list position, material
     const float4* sph_filter;
     const float*  sph_scale;
+    const float4* filter_img;
     const float4* rect_a;   // cx, cy, cz, du
     const float4* rect_b;   // dv, -, -, -
     const int2*   rect_meta;

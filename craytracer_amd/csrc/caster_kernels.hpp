@@ -25,6 +25,7 @@ CDEV SceneView view_of(const SceneDev& s)
     v.imgs = reinterpret_cast<const Img*>(s.imgs);
     v.n_sph = s.n_sph; v.n_rect = s.n_rect; v.n_mat = s.n_mat; v.n_img = s.n_img;
     v.noise_vec = s.noise_vec; v.noise_perm = s.noise_perm;
+    v.filter_img = s.filter_img[CASTER_STRICT];
     v.n_always = s.n_always;
     for (int k = 0; k < kMaxAlways; ++k) v.always[k] = s.always[k];
     return v;

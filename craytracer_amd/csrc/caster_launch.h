@@ -21,12 +21,15 @@ struct ImgRec {
 struct CamRec { float o[3], llc[3], h[3], v[3], u0[3], v0[3]; float lr; };
 
 constexpr int kMaxAlways = 4;
+constexpr float kFilterMarginStrict = 1.0e-5f;   // candidate-filter margins of the two arithmetic modes
+constexpr float kFilterMarginFast = 2.5e-6f;
 
 struct SceneDev {
     const float4* sph;       // cx, cy, cz, r            (list order among spheres)
     const int2*   sph_meta;  // list position, material
     const float4* sph_filter;// candidate filter: cx-Px, cy-Py, cz-Pz, C - r*r   (C = |c-P|^2; -inf = always a candidate, +inf = never: listed in `always`)
     const float*  sph_scale; // C + r*r, the scale of the filter's rounding error
+    const float4* filter_img[2]; // the filter entries as the loop reads them (fast, strict), padded with 16 never-candidates
     const float4* rect_a;    // cx, cy, cz, du
     const float4* rect_b;    // dv, 0, 0, 0
     const int2*   rect_meta;

@@ -195,13 +195,14 @@ CDEV acc_t to_fixed(float x)
 }
 
 // ---- sphere loop ---------------------------------------------------------
-// LDS holds two images of the sphere tile:
-//   filter[k] = {cx-Px, cy-Py, g*(C+r*r)-(C-r*r), cz-Pz}, with C = |c-P|^2 and
-//               P a reference point near the scene's spheres;
-//   exact[k]  = {cx, cy, r*r, cz}: the operands of the reference's test
-//               (src/caster.c:101-105).
-// The value order puts each operand where a packed instruction can broadcast
-// it to both halves of a register pair.
+// Two tables describe the spheres:
+//   filter[k] = {cx-Px, cy-Py, g*(C+r*r)-(C-r*r), cz-Pz}, with C = |c-P|^2 and P a reference
+//               point near the scene's spheres: built by the host, read by every wave through
+//               the scalar cache (the entries are wave-uniform and live in SGPRs);
+//   exact[k]  = {cx, cy, r*r, cz}: the operands of the reference's test (src/caster.c:101-105),
+//               a tile of them staged in LDS for the candidate code.
+// The value order puts each operand where a packed instruction can broadcast it to both
+// halves of a register pair.
 //
 // Every ray meets every sphere (the reference has no early out), but only a
 // few spheres per ray can be hit.  The loop therefore evaluates, for both slots
@@ -216,26 +217,18 @@ CDEV acc_t to_fixed(float x)
 // every ray and are tested directly (test_always).
 constexpr int kGroup = 4;               // spheres per software-pipeline stage
 #if CASTER_STRICT
-constexpr float kFilterMargin = 1.0e-5f;
+constexpr float kFilterMargin = kFilterMarginStrict;
 #else
-constexpr float kFilterMargin = 2.5e-6f;
+constexpr float kFilterMargin = kFilterMarginFast;
 #endif
 constexpr int kLdsSlack = 2 * kGroup;   // read-ahead beyond the padded tile
 
 CDEV float4 exact_image(const float4 s /* cx, cy, cz, r */) { return make_float4(s.x, s.y, s.w * s.w, s.z); }
 // Pad entries: r*r = -1e30 gives a finite negative discriminant for every ray.
 CDEV float4 exact_pad() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
-CDEV float4 filter_pad() { return make_float4(0.0f, 0.0f, -1.0e30f, 0.0f); }
-// Host table entry {c'x, c'y, c'z, K = C - r*r}; K = -inf: always a candidate; K = +inf: never (the
-// sphere is tested directly, see test_always), stored like a pad entry.
-CDEV float4 filter_image(const float4 h, const float scale /* C + r*r */)
-{
-    return make_float4(h.x, h.y, (h.w == INFINITY) ? -1.0e30f : kFilterMargin * scale - h.w, h.z);
-}
-
 struct SphereLds {
     const float4* exact;
-    const float4* filter;
+    const float4* filter; // the whole scene's filter entries, in device memory (read through the scalar cache)
     int count;            // spheres in the tile, without the padding
 };
 
@@ -284,9 +277,13 @@ CDEV f2 candidate_key(const PairRays& r, const float4 f /* c'x, c'y, g*scale - K
     f2 a = r.ux * splat(f.x);
     a = __builtin_elementwise_fma(r.uy, splat(f.y), a);
     a = __builtin_elementwise_fma(r.uz, splat(f.w), a);
-    f2 b = __builtin_elementwise_fma(r.p2x, splat(f.x), splat(f.z));
+    // b = p2z * c'z + K: both scalars sit in one SGPR pair, which a single instruction may read twice
+    // (left to itself the compiler copies K to a VGPR first: one more VALU instruction per sphere)
+    f2 b;
+    const f2 zw = {f.z, f.w};
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(b) : "v"(r.p2z), "s"(zw));
     b = __builtin_elementwise_fma(r.p2y, splat(f.y), b);
-    b = __builtin_elementwise_fma(r.p2z, splat(f.w), b);
+    b = __builtin_elementwise_fma(r.p2x, splat(f.x), b);
     return __builtin_elementwise_fma(a, a, b);
 }
 
@@ -399,11 +396,19 @@ struct Group {
     float4 g0, g1, g2, g3;
 };
 
-CDEV Group load_group(const float4* src, int k)
+// The filter entries are the same for every lane: they are read through the scalar cache into
+// SGPRs (constant address space -> s_load_dwordx16 per group) and enter the packed instructions
+// as scalar operands.  Against a broadcast read from LDS this saves the vector-register writes and
+// 32 VGPRs, and measured 5 % of the frame time.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) v4f* filter_ptr;
+CDEV float4 entry(filter_ptr src, int k) { const v4f v = src[k]; return make_float4(v.x, v.y, v.z, v.w); }
+
+CDEV Group load_group(filter_ptr src, int k)
 {
     Group g;
-    g.g0 = src[k]; g.g1 = src[k + 1];
-    g.g2 = src[k + 2]; g.g3 = src[k + 3];
+    g.g0 = entry(src, k); g.g1 = entry(src, k + 1);
+    g.g2 = entry(src, k + 2); g.g3 = entry(src, k + 3);
     return g;
 }
 
@@ -450,7 +455,7 @@ CDEV void process_group(const Group& g, int k, const PairRays& r, CandLists& cl,
 CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, CandLists& cl,
                      const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
 {
-    const float4* src = lds.filter;
+    filter_ptr src = (filter_ptr)(lds.filter + base);
     Group ga = load_group(src, 0);
 #pragma unroll 1
     for (int k = 0; k < cnt; k += 2 * kGroup) {
@@ -483,15 +488,13 @@ CDEV void non_finite_rule(bool finite, int n_sph, float& closest, int& best)
     if (!finite) { closest = __builtin_nanf(""); best = n_sph - 1; }
 }
 
-// Copies spheres [base, base+cnt) into LDS, padded to a multiple of 2*kGroup
+// Copies the exact image of spheres [base, base+cnt) into LDS, padded to a multiple of 2*kGroup
 // plus the read-ahead slack.  Returns the padded count.
-CDEV int stage_spheres(float4* exact, float4* filter, const SceneView& sc, int base, int cnt)
+CDEV int stage_spheres(float4* exact, const SceneView& sc, int base, int cnt)
 {
     const int padded = (cnt + 2 * kGroup - 1) / (2 * kGroup) * (2 * kGroup);
-    for (int k = threadIdx.x; k < padded + kLdsSlack; k += kBlock) {
+    for (int k = threadIdx.x; k < padded + kLdsSlack; k += kBlock)
         exact[k] = (k < cnt) ? exact_image(sc.sph[base + k]) : exact_pad();
-        filter[k] = (k < cnt) ? filter_image(sc.sph_filter[base + k], sc.sph_scale[base + k]) : filter_pad();
-    }
     return padded;
 }
 
@@ -591,8 +594,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
     unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * kAccStride);
     float4* s_exact = reinterpret_cast<float4*>(s_dyn + kLdsFixedBytes);
-    float4* s_filter = s_exact + a.lds_spheres;
-    float4* s_noise_vec = s_filter + a.lds_spheres;                             // only if the scene has noise tables
+    float4* s_noise_vec = s_exact + a.lds_spheres;                              // only if the scene has noise tables
     unsigned char* s_noise_perm = reinterpret_cast<unsigned char*>(s_noise_vec + 256);
 
     SceneView sc = view_of(a.scene);
@@ -613,10 +615,10 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     acc_t* wave_acc = s_acc + wave * kAccStride;
     for (int k = lane; k < kAccStride; k += 64) wave_acc[k] = 0;
     int n_lds = 0;
-    if (!TILED) n_lds = stage_spheres(s_exact, s_filter, sc, 0, sc.n_sph);
+    if (!TILED) n_lds = stage_spheres(s_exact, sc, 0, sc.n_sph);
     SphereLds lds;
     lds.exact = s_exact;
-    lds.filter = s_filter;
+    lds.filter = sc.filter_img;
     lds.count = sc.n_sph;
     const float3 ref = make_float3(a.scene.ref[0], a.scene.ref[1], a.scene.ref[2]);
     __syncthreads();
@@ -737,7 +739,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
             for (int base = 0; base < sc.n_sph; base += kSphTile) {
                 const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
                 if (base) __syncthreads();           // everyone is done with the previous tile
-                const int padded = stage_spheres(s_exact, s_filter, sc, base, cnt);
+                const int padded = stage_spheres(s_exact, sc, base, cnt);
                 lds.count = cnt;
                 __syncthreads();
                 isect_tile(lds, padded, base, pr, cl, sa, sb, closestA, closestB, bestA, bestB);
@@ -795,7 +797,7 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     if (units <= 0 || units > 0x7fffffffLL) return hipErrorInvalidValue;
     a.n_units = (int)units;
     a.lds_spheres = lds_sphere_slots(a.scene.n_sph);
-    const size_t lds_bytes = kLdsFixedBytes + 2 * sizeof(float4) * (size_t)a.lds_spheres +
+    const size_t lds_bytes = kLdsFixedBytes + sizeof(float4) * (size_t)a.lds_spheres +
                              (a.scene.noise_vec ? kNoiseLdsBytes : 0);
     long long blocks = (units + kWaves - 1) / kWaves;
     if (blocks > resident_blocks) blocks = resident_blocks;      // persistent: the waves loop over the queue
@@ -814,12 +816,11 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
                                 float* n3, int32_t* face, int32_t* mat)
 {
     __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
-    __shared__ float4 s_filter[kSphTile + 2 * kLdsSlack];
     __shared__ unsigned short s_cand[kWaves * kListCap * 64];
     const SceneView sc = view_of(sd);
     SphereLds lds;
     lds.exact = s_exact;
-    lds.filter = s_filter;
+    lds.filter = sc.filter_img;
     lds.count = 0;
     const float3 ref = make_float3(sd.ref[0], sd.ref[1], sd.ref[2]);
     const int i0 = (blockIdx.x * kBlock + threadIdx.x) * 2;
@@ -854,7 +855,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
     for (int base = 0; base < sc.n_sph; base += kSphTile) {
         const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
         __syncthreads();
-        const int padded = stage_spheres(s_exact, s_filter, sc, base, cnt);
+        const int padded = stage_spheres(s_exact, sc, base, cnt);
         lds.count = cnt;
         __syncthreads();
         isect_tile(lds, padded, base, pr, cl, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);

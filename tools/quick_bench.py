@@ -8,6 +8,15 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import craytracer_amd.binding as _b  # noqa: E402
+
+if "--lib" in sys.argv:     # a build variant of libcaster_hip (developer A/B runs)
+    _i = sys.argv.index("--lib")
+    _variant = sys.argv[_i + 1]
+    del sys.argv[_i:_i + 2]
+    _paths = _b.lib_paths()
+    _paths["caster"] = os.path.join(os.path.dirname(_paths["caster"]), _variant)
+    _b.lib_paths = lambda: _paths
 import craytracer_amd as ca  # noqa: E402
 
 ap = argparse.ArgumentParser()
