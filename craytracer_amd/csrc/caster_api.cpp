@@ -156,7 +156,7 @@ int caster_hip_create(int device, caster_hip_ctx** out)
         // persistent grid: 4 blocks of 4 waves per CU (the kernel is built for 4 waves per SIMD)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            ctx->resident_blocks = prop.multiProcessorCount * 4;
+            ctx->resident_blocks = prop.multiProcessorCount * 4;     // CASTER_BLOCKS_PER_CU of caster_render.hpp
     }
     const char* env_chunk = getenv("CASTER_HIP_CHUNK");
     if (env_chunk) ctx->chunk = atoi(env_chunk);

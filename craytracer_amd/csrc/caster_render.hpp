@@ -379,8 +379,12 @@ CDEV void drain_candidates(CandLists& cl, const SphereLds& lds, int base, const 
             const float tmin = second ? sb.tmin : sa.tmin;
             float t;
             if (candidate_root(lds.exact[k], o, d, aa, tmin, t)) {
-                if (second) take_hit(t, base + k, closestB, bestB);
-                else take_hit(t, base + k, closestA, bestA);
+                // selects on values, not on which variable to update: the four stay in registers
+                float closest = second ? closestB : closestA;
+                int best = second ? bestB : bestA;
+                take_hit(t, base + k, closest, best);
+                closestA = second ? closestA : closest; bestA = second ? bestA : best;
+                closestB = second ? closest : closestB; bestB = second ? best : bestB;
             }
         }
     }
@@ -584,8 +588,13 @@ CDEV void swap_slots(Slot& a, Slot& b)
     b = t;
 }
 
+// Resident blocks per CU = waves per SIMD.  Measured on the 1080p benchmark (strict, ms per frame):
+// 3 (168 VGPRs, no spills) 291, 4 (128 VGPRs) 276, 5 (96 VGPRs) 290, 6 (80 VGPRs) 314.
+#ifndef CASTER_BLOCKS_PER_CU
+#define CASTER_BLOCKS_PER_CU 4
+#endif
 template <bool TILED>
-__global__ __launch_bounds__(kBlock, 4)
+__global__ __launch_bounds__(kBlock, CASTER_BLOCKS_PER_CU)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -657,7 +666,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
 #endif
 
     unsigned int trip = 0;
-    const unsigned int age = blockIdx.x * 4u / gridDim.x;       // blocks are placed in launch order, four per CU
+    const unsigned int age = blockIdx.x * (unsigned)CASTER_BLOCKS_PER_CU / gridDim.x;       // blocks are placed in launch order, four per CU
     // The unit that feeds the slots.  When its pool is empty its sums so far go to the frame buffer
     // and the wave starts on the next unit at once; the paths still in flight then belong to a tile
     // that is no longer the current one and deposit their radiance in the frame buffer themselves.
