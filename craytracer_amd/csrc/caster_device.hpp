@@ -85,9 +85,17 @@ struct SceneView {
     int n_sph, n_rect, n_mat, n_img;
     int n_always;
     int always[4];          // spheres tested directly for every ray
-    const float4* noise_vec;    // Perlin tables (in LDS inside the render kernel), or null
-    const uint8_t* noise_perm;
+    // Perlin tables, staged in LDS by every kernel that evaluates textures (stage_noise).  An LDS
+    // address may be 0, which is also the null value of that address space: has_noise says
+    // whether the tables are there.
+    bool has_noise;
+    const __attribute__((address_space(3))) float4* noise_vec;
+    const __attribute__((address_space(3))) uint8_t* noise_perm;
 };
+
+typedef __attribute__((address_space(3))) float4* lds_float4_ptr;
+typedef __attribute__((address_space(3))) uint8_t* lds_u8_ptr;
+constexpr int kNoiseLdsBytes = 256 * (int)sizeof(float4) + 768;    // Perlin vectors and permutation tables
 
 CDEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 CDEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }   // common.c:45-53
@@ -386,9 +394,9 @@ CDEV float noise_value(const SceneView& sc, V3 p)
     const float uu = u * u * (3.0f - 2.0f * u);
     const float vv = v * v * (3.0f - 2.0f * v);
     const float ww = w * w * (3.0f - 2.0f * w);
-    const uint8_t* px = sc.noise_perm;
-    const uint8_t* py = px + 256;
-    const uint8_t* pz = px + 512;
+    const __attribute__((address_space(3))) uint8_t* px = sc.noise_perm;
+    const __attribute__((address_space(3))) uint8_t* py = px + 256;
+    const __attribute__((address_space(3))) uint8_t* pz = px + 512;
     float accum = 0.0f;
 #pragma unroll
     for (int di = 0; di < 2; di++) {
@@ -400,10 +408,11 @@ CDEV float noise_value(const SceneView& sc, V3 p)
             const float wj = dj ? vv : 1.0f - vv;
 #pragma unroll
             for (int dk = 0; dk < 2; dk++) {
-                const float4 c = sc.noise_vec[hxy ^ pz[(k + dk) & 255]];
+                const __attribute__((address_space(3))) float4* cp = sc.noise_vec + (hxy ^ pz[(k + dk) & 255]);
+                const float cx = cp->x, cy = cp->y, cz = cp->z;
                 const float wk = dk ? ww : 1.0f - ww;
                 const float ox = u - (float)di, oy = v - (float)dj, oz = w - (float)dk;
-                const float d = (c.x * ox + c.y * oy) + c.z * oz;
+                const float d = (cx * ox + cy * oy) + cz * oz;
                 accum += ((wi * wj) * wk) * d;
             }
         }
@@ -415,6 +424,7 @@ CDEV float noise_turb(const SceneView& sc, V3 p)
 {
     float accum = 0.0f, weight = 1.0f;
     V3 temp = p;
+#pragma unroll 1
     for (int k = 0; k < 7; k++) {
         accum += weight * noise_value(sc, temp);
         weight *= 0.5f;
@@ -448,7 +458,7 @@ CDEV V3 texture_color(const SceneView& sc, const Mat& m, HitRec& rec)           
         return mk(color_scale * (float)pix[0], color_scale * (float)pix[1], color_scale * (float)pix[2]);
     }
     case 4: { // TTYPE_NOISE (extension): marble
-        if (!sc.noise_vec) return mk(0.0f, 0.0f, 0.0f);
+        if (!sc.has_noise) return mk(0.0f, 0.0f, 0.0f);
         const float s = 0.5f * (1.0f + m_sin(m.c1[0] * rec.p.z + 10.0f * noise_turb(sc, rec.p)));
         return mk(m.c0[0] * s, m.c0[1] * s, m.c0[2] * s);
     }
@@ -483,35 +493,44 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
     // shared: the wave runs it once for the lanes of both materials.
     V3 us = mk(0.0f, 0.0f, 0.0f);
     if (m.type == 0 || m.type == 1) us = random_unit_sphere(g);
+    // The texture is looked up once, after the switch, for the lanes of every material that wants
+    // it: the wave then runs the lookup (a long one for noise textures) once, not per material.
+    bool cont = false, textured = false;
     switch (m.type) {
     case 0: // MTYPE_LAMBERTIAN, material.c:3-12
         CASTER_STAT(7);
         next.o = rec.p;
         next.d = rec.n + to_unit(us);
         if (near_zero(next.d)) next.d = rec.n;
-        atten = texture_color(sc, m, rec);
-        return true;
+        cont = true;
+        textured = true;
+        break;
     case 1: // MTYPE_METAL, material.c:14-19
         CASTER_STAT(8);
         next.o = rec.p;
         next.d = reflect(to_unit(r.d), rec.n) + us * m.fuzz;
-        if (dot(next.d, rec.n) > 0.0f) {
-            atten = texture_color(sc, m, rec);
-            return true;
-        }
-        return false;
+        cont = dot(next.d, rec.n) > 0.0f;
+        textured = cont;
+        break;
     case 2: // MTYPE_DIELECTRIC
         CASTER_STAT(9);
         scatter_dielectric(g, r, rec, m.ior, next);
-        return true;
-    case 3: // MTYPE_DIFF_LIGHT
+        cont = true;
+        break;
+    case 3: // MTYPE_DIFF_LIGHT, caster.c:470-479
         CASTER_STAT(10);
         if (m.tex == 0) emit = mk(m.c0[0], m.c0[1], m.c0[2]);
-        else if (m.tex == 2) emit = texture_color(sc, m, rec);
-        return false;
+        else if (m.tex == 2) textured = true;
+        break;
     default:
-        return false;
+        break;
     }
+    if (textured) {
+        const V3 c = texture_color(sc, m, rec);
+        if (m.type == 3) emit = c;
+        else atten = c;
+    }
+    return cont;
 }
 
 }  // namespace caster

@@ -24,11 +24,26 @@ CDEV SceneView view_of(const SceneDev& s)
     v.mats = reinterpret_cast<const Mat*>(s.mats);
     v.imgs = reinterpret_cast<const Img*>(s.imgs);
     v.n_sph = s.n_sph; v.n_rect = s.n_rect; v.n_mat = s.n_mat; v.n_img = s.n_img;
-    v.noise_vec = s.noise_vec; v.noise_perm = s.noise_perm;
+    v.has_noise = false; v.noise_vec = nullptr; v.noise_perm = nullptr;      // see stage_noise
     v.filter_img = s.filter_img[CASTER_STRICT];
     v.n_always = s.n_always;
     for (int k = 0; k < kMaxAlways; ++k) v.always[k] = s.always[k];
     return v;
+}
+
+// Copies the scene's Perlin tables (if it has any) into the kernel's LDS block `lds` of
+// kNoiseLdsBytes and points the view at the copy.  Every thread of the block must call it; a
+// __syncthreads() has to follow before the first texture evaluation.
+CDEV void stage_noise(SceneView& v, const SceneDev& s, unsigned char* lds)
+{
+    if (!s.noise_vec) return;
+    float4* vec = reinterpret_cast<float4*>(lds);
+    unsigned char* perm = lds + 256 * sizeof(float4);
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) vec[k] = s.noise_vec[k];
+    for (int k = threadIdx.x; k < 768; k += blockDim.x) perm[k] = s.noise_perm[k];
+    v.has_noise = true;
+    v.noise_vec = (lds_float4_ptr)vec;
+    v.noise_perm = (lds_u8_ptr)perm;
 }
 
 CDEV Cam cam_of(const CamRec& c)
@@ -200,9 +215,12 @@ __global__ void CASTER_NAME(k_test_camera_)(CamRec cr, int n, const float* uv2, 
 __global__ void CASTER_NAME(k_test_texture_)(SceneDev sd, int n, const int32_t* mat, const float* uv2,
                                              const float* p3, float* rgb3)
 {
+    __shared__ __align__(16) unsigned char s_noise[kNoiseLdsBytes];
+    SceneView sc = view_of(sd);
+    stage_noise(sc, sd, s_noise);
+    __syncthreads();
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const SceneView sc = view_of(sd);
     HitRec rec;
     rec.p = mk(p3[3 * k], p3[3 * k + 1], p3[3 * k + 2]);
     rec.uv.u = uv2[2 * k]; rec.uv.v = uv2[2 * k + 1];

@@ -108,7 +108,6 @@ constexpr int kAccStride = kTileW * kTileH * 3;     // one accumulator set: 64 p
 typedef unsigned long long acc_t;                   // fixed point, 32 fractional bits
 // LDS in front of the sphere images: accumulators, candidate lists
 constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * kAccStride + 2 * kWaves * kListCap * 64;
-constexpr int kNoiseLdsBytes = 256 * (int)sizeof(float4) + 768;    // Perlin vectors and permutation tables
 constexpr double kAccScale = 4294967296.0;
 
 // Pulls the next unit off the queue.  Units are numbered chunk-major.
@@ -604,16 +603,9 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * kAccStride);
     float4* s_exact = reinterpret_cast<float4*>(s_dyn + kLdsFixedBytes);
     float4* s_noise_vec = s_exact + a.lds_spheres;                              // only if the scene has noise tables
-    unsigned char* s_noise_perm = reinterpret_cast<unsigned char*>(s_noise_vec + 256);
 
     SceneView sc = view_of(a.scene);
-    if (a.scene.noise_vec) {
-        // the Perlin tables are read 98 times per shaded noise texel: keep them in LDS
-        for (int k = threadIdx.x; k < 256; k += kBlock) s_noise_vec[k] = a.scene.noise_vec[k];
-        for (int k = threadIdx.x; k < 768; k += kBlock) s_noise_perm[k] = a.scene.noise_perm[k];
-        sc.noise_vec = s_noise_vec;
-        sc.noise_perm = s_noise_perm;
-    }
+    stage_noise(sc, a.scene, reinterpret_cast<unsigned char*>(s_noise_vec));   // read 98 times per shaded noise texel
     const Cam cam = cam_of(a.cam);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
