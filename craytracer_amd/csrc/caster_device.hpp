@@ -358,11 +358,11 @@ CDEV bool scatter_metal(Rng& g, const Ray& r, const HitRec& rec, float fuzz, Ray
     return dot(out.d, rec.n) > 0.0f;
 }
 
-CDEV bool scatter_dielectric(Rng& g, const Ray& r, const HitRec& rec, float ior, Ray& out)  // material.c:21-43
+// material.c:21-43 with unit_vector(r->direction) handed in (shade() computes it once for all materials)
+CDEV bool scatter_dielectric_unit(Rng& g, V3 udir, const HitRec& rec, float ior, Ray& out)
 {
     float rratio = rec.f ? (1.0f / ior) : ior;
     out.o = rec.p;
-    V3 udir = to_unit(r.d);
     V3 iudir = neg(udir);
     float cos_theta = fminf(dot(iudir, rec.n), 1.0f);
     float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
@@ -372,6 +372,11 @@ CDEV bool scatter_dielectric(Rng& g, const Ray& r, const HitRec& rec, float ior,
     else
         out.d = refract(udir, rec.n, rratio, cos_theta);
     return true;
+}
+
+CDEV bool scatter_dielectric(Rng& g, const Ray& r, const HitRec& rec, float ior, Ray& out)  // material.c:21-43
+{
+    return scatter_dielectric_unit(g, to_unit(r.d), rec, ior, out);
 }
 
 CDEV float clampf(float x, float lo, float hi)                  // common.c:25-29
@@ -493,6 +498,11 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
     // shared: the wave runs it once for the lanes of both materials.
     V3 us = mk(0.0f, 0.0f, 0.0f);
     if (m.type == 0 || m.type == 1) us = random_unit_sphere(g);
+    // Each scatter function normalises one vector first: the unit-sphere sample (lambertian,
+    // material.c:6 through random_unit_norm) or the incoming direction (metal :16, dielectric :24).
+    // One normalisation serves the lanes of all three.
+    V3 unit = mk(0.0f, 0.0f, 0.0f);
+    if (m.type >= 0 && m.type <= 2) unit = to_unit(m.type == 0 ? us : r.d);
     // The texture is looked up once, after the switch, for the lanes of every material that wants
     // it: the wave then runs the lookup (a long one for noise textures) once, not per material.
     bool cont = false, textured = false;
@@ -500,7 +510,7 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
     case 0: // MTYPE_LAMBERTIAN, material.c:3-12
         CASTER_STAT(7);
         next.o = rec.p;
-        next.d = rec.n + to_unit(us);
+        next.d = rec.n + unit;
         if (near_zero(next.d)) next.d = rec.n;
         cont = true;
         textured = true;
@@ -508,13 +518,13 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
     case 1: // MTYPE_METAL, material.c:14-19
         CASTER_STAT(8);
         next.o = rec.p;
-        next.d = reflect(to_unit(r.d), rec.n) + us * m.fuzz;
+        next.d = reflect(unit, rec.n) + us * m.fuzz;
         cont = dot(next.d, rec.n) > 0.0f;
         textured = cont;
         break;
     case 2: // MTYPE_DIELECTRIC
         CASTER_STAT(9);
-        scatter_dielectric(g, r, rec, m.ior, next);
+        scatter_dielectric_unit(g, unit, rec, m.ior, next);
         cont = true;
         break;
     case 3: // MTYPE_DIFF_LIGHT, caster.c:470-479
