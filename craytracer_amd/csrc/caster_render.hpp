@@ -108,7 +108,6 @@ constexpr int kAccStride = kTileW * kTileH * 3;     // one accumulator set: 64 p
 typedef unsigned long long acc_t;                   // fixed point, 32 fractional bits
 // LDS in front of the sphere images: accumulators, candidate lists
 constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * kAccStride + 2 * kWaves * kListCap * 64;
-constexpr double kAccScale = 4294967296.0;
 
 // Pulls the next unit off the queue.  Units are numbered chunk-major.
 CDEV Unit fetch_unit(const RenderArgs& a, int tiles_x, int n_tiles, int lane)
@@ -186,11 +185,18 @@ CDEV void flush_unit(const Unit& un, acc_t* acc_set, const RenderArgs& a, int la
     __builtin_amdgcn_wave_barrier();
 }
 
+// floor(x * 2^32) for a radiance value: a product of colours and an emission, finite and >= 0 for
+// any sane scene (clamped to [0, 1e9], NaN -> 0).  Integer arithmetic on the float's fields: the
+// result equals (u64)((double)x * 2^32) bit for bit without the slow double-to-u64 conversion.
 CDEV acc_t to_fixed(float x)
 {
-    // radiance is a product of colours and an emission: finite and >= 0 for any sane scene
-    const double d = (double)fminf(fmaxf(x, 0.0f), 1.0e9f) * kAccScale;
-    return (acc_t)d;
+    const unsigned int b = __float_as_uint(fminf(fmaxf(x, 0.0f), 1.0e9f));
+    const int e = (int)(b >> 23);                               // biased exponent, <= 156
+    const unsigned long long m = e ? (unsigned long long)((b & 0x7FFFFFu) | 0x800000u) : 0ull;   // denormals are < 2^-32
+    const int sh = e - 118;                                     // x * 2^32 = m * 2^(e - 150 + 32)
+    const int left = sh > 0 ? sh : 0;
+    const int right = sh < 0 ? (-sh < 63 ? -sh : 63) : 0;
+    return (m << left) >> right;
 }
 
 // ---- sphere loop ---------------------------------------------------------
@@ -534,16 +540,17 @@ CDEV void deposit(int q, V3 radiance, const TileGeom& tg, acc_t* wave_acc, const
 {
     const int i = q & 0xFFFF, j = (int)((unsigned int)q >> 16);
     const unsigned int qx = (unsigned int)(i - tg.x0), qy = (unsigned int)(j - tg.y0);
+    const acc_t fr = to_fixed(radiance.x), fg = to_fixed(radiance.y), fb = to_fixed(radiance.z);
     if (qx < (unsigned int)tg.tw && qy < (unsigned int)tg.th) {
         acc_t* px = wave_acc + (qy * kTileW + qx) * 3;
-        if (radiance.x != 0.0f) atomicAdd(px + 0, to_fixed(radiance.x));
-        if (radiance.y != 0.0f) atomicAdd(px + 1, to_fixed(radiance.y));
-        if (radiance.z != 0.0f) atomicAdd(px + 2, to_fixed(radiance.z));
+        if (fr) atomicAdd(px + 0, fr);
+        if (fg) atomicAdd(px + 1, fg);
+        if (fb) atomicAdd(px + 2, fb);
     } else {
         acc_t* px = a.fixed + 4 * ((size_t)j * a.width + i);
-        if (radiance.x != 0.0f) atomicAdd(px + 0, to_fixed(radiance.x));
-        if (radiance.y != 0.0f) atomicAdd(px + 1, to_fixed(radiance.y));
-        if (radiance.z != 0.0f) atomicAdd(px + 2, to_fixed(radiance.z));
+        if (fr) atomicAdd(px + 0, fr);
+        if (fg) atomicAdd(px + 1, fg);
+        if (fb) atomicAdd(px + 2, fb);
     }
 }
 
