@@ -102,8 +102,10 @@ int caster_hip_destroy(caster_hip_ctx* ctx);
 /* Kernels are launched on this hipStream_t (NULL = the default stream). */
 int caster_hip_set_stream(caster_hip_ctx* ctx, void* hip_stream);
 
-/* Tuning knob: samples of one pixel tile handled by one work unit (0 = default).
- * It changes scheduling only; the rendered paths do not depend on it. */
+/* Tuning knob: samples of one 8x8 pixel tile handled by one work unit.  0 (the default) lets the
+ * library plan the chunks itself: up to 64 samples first, smaller ones towards the end of the
+ * call so that the waves finish together.  It changes scheduling only; the rendered paths and
+ * the sums do not depend on it. */
 int caster_hip_set_chunk(caster_hip_ctx* ctx, int samples_per_unit);
 
 /* Replaces the pointer-chasing hit_list the dispatcher holds (inc/dispatcher.h:31):
