@@ -217,9 +217,13 @@ def recorded_traffic(workload, mode, world):
     """HBM bytes per launch of the render kernel.  Counters cannot be read from inside a timed run:
     the figure is the one measured with rocprofv3 --pmc passes for this exact workload, kept under
     profiles/ together with how it was taken; None for any other workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_hbm_traffic.json")
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*hbm_traffic.json")))
+    if not paths:
+        return None
     try:
-        with open(path) as f:
+        with open(paths[-1]) as f:      # the latest measurement
             rec = json.load(f)
     except (OSError, ValueError):
         return None
