@@ -32,17 +32,55 @@ __device__ unsigned long long g_caster_stats[32];
 #else
 #define CASTER_STAT(i) do { } while (0)
 #endif
+// Region timers of the render kernel.  In the product build every member is an empty inline
+// function and the object holds nothing.
 #ifdef CASTER_TIMERS
-__device__ unsigned long long g_caster_wavelog[4096 * 16];   // per resident wave: start, end (100 MHz), units, trips, last fetch time, last unit, time the queue was found empty, trips then
-#define CASTER_TIC(v) const unsigned long long v = __builtin_readcyclecounter()
-#define CASTER_TOC(v, acc) acc += __builtin_readcyclecounter() - v
-#define CASTER_TIME_DECL(acc) unsigned long long acc = 0
-#define CASTER_TIME_OUT(acc, i) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_caster_stats[16 + (i)], acc); } while (0)
+__device__ unsigned long long g_caster_wavelog[4096 * 16];  // one record per resident wave, see WaveTimers::report
+struct WaveTimers {
+    enum Region { kSchedule = 0, kBounce, kRefill, kIntersect, kTotal, kLists, kRegions };
+    unsigned long long ticks[kRegions] = {0, 0, 0, 0, 0, 0};   // shader clock ticks per region
+    unsigned long long trips = 0, units = 0;
+    unsigned long long wall0 = 0, wall_last_fetch = 0, wall_empty = 0;  // 100 MHz
+    unsigned long long last_unit = 0, trips_at_empty = 0;
+    __device__ __forceinline__ unsigned long long now() const { return __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void start() { wall0 = wall_clock64(); }
+    __device__ __forceinline__ void add(Region r, unsigned long long t0) { ticks[r] += now() - t0; }
+    __device__ __forceinline__ void trip() { ++trips; }
+    __device__ __forceinline__ void fetched(bool got, int chunk, int tile_x, int tile_y)
+    {
+        if (got) { ++units; wall_last_fetch = wall_clock64(); last_unit = (unsigned long long)chunk * 1000000ull + tile_y * 1000 + tile_x; }
+        else { wall_empty = wall_clock64(); trips_at_empty = trips; }
+    }
+    // sums into g_caster_stats[16..22] (+ trips into [0] when the event counters are off) and one record
+    // per wave: start, end, units, trips, last fetch, last unit, queue-empty time, trips then,
+    // bounce, refill, intersect, lists, total ticks, rays
+    __device__ __forceinline__ void report(int wave_in_block, unsigned int wave_rays)
+    {
+        if ((threadIdx.x & 63) != 0) return;
+        for (int r = 0; r < kRegions; ++r) atomicAdd(&g_caster_stats[16 + r], ticks[r]);
+        const unsigned long long wall1 = wall_clock64();
+        atomicAdd(&g_caster_stats[16 + kRegions], wall1 - wall0);
+#ifndef CASTER_STATS
+        atomicAdd(&g_caster_stats[0], trips);
+#endif
+        if (blockIdx.x >= 1024) return;
+        unsigned long long* wl = g_caster_wavelog + (blockIdx.x * 4 + wave_in_block) * 16;
+        wl[0] = wall0; wl[1] = wall1; wl[2] = units; wl[3] = trips;
+        wl[4] = wall_last_fetch; wl[5] = last_unit; wl[6] = wall_empty; wl[7] = trips_at_empty;
+        wl[8] = ticks[kBounce]; wl[9] = ticks[kRefill]; wl[10] = ticks[kIntersect]; wl[11] = ticks[kLists];
+        wl[12] = ticks[kTotal]; wl[13] = wave_rays;
+    }
+};
 #else
-#define CASTER_TIC(v) do { } while (0)
-#define CASTER_TOC(v, acc) do { } while (0)
-#define CASTER_TIME_DECL(acc) do { } while (0)
-#define CASTER_TIME_OUT(acc, i) do { } while (0)
+struct WaveTimers {
+    enum Region { kSchedule = 0, kBounce, kRefill, kIntersect, kTotal, kLists, kRegions };
+    __device__ __forceinline__ unsigned long long now() const { return 0; }
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void add(Region, unsigned long long) {}
+    __device__ __forceinline__ void trip() {}
+    __device__ __forceinline__ void fetched(bool, int, int, int) {}
+    __device__ __forceinline__ void report(int, unsigned int) {}
+};
 #endif
 
 namespace caster {

@@ -350,15 +350,12 @@ CDEV void take_hit(float t, int index, float& closest, int& best)
 struct CandLists {
     unsigned short* mem;    // [kListCap][64], this wave's; entry i of a lane at mem[i * 64 + lane]
     int cnt;                // entries in this lane's list
-#ifdef CASTER_TIMERS
-    unsigned long long ticks;
-#endif
 };
 
 CDEV void drain_candidates(CandLists& cl, const SphereLds& lds, int base, const Slot& sa, const Slot& sb,
-                           float& closestA, float& closestB, int& bestA, int& bestB)
+                           float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
 {
-    CASTER_TIC(tq);
+    const unsigned long long t0 = tm.now();
     int cur = 0;
     unsigned int bits = 0, group = 0;
     for (;;) {
@@ -394,9 +391,7 @@ CDEV void drain_candidates(CandLists& cl, const SphereLds& lds, int base, const 
         }
     }
     cl.cnt = 0;
-#ifdef CASTER_TIMERS
-    CASTER_TOC(tq, cl.ticks);
-#endif
+    tm.add(WaveTimers::kLists, t0);
 }
 
 // A pipeline stage: kGroup spheres held in named registers (no indexed array,
@@ -429,7 +424,8 @@ CDEV unsigned int push_sign(unsigned int m, float x) { return __builtin_amdgcn_a
 // key per slot (max3 chains) replaces two compares per sphere.  A non-finite ray has NaN
 // thresholds and is never a candidate.
 CDEV void process_group(const Group& g, int k, const PairRays& r, CandLists& cl, const SphereLds& lds, int base,
-                        const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
+                        const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
+                        WaveTimers& tm)
 {
     const f2 k0 = candidate_key(r, g.g0);
     const f2 k1 = candidate_key(r, g.g1);
@@ -440,7 +436,7 @@ CDEV void process_group(const Group& g, int k, const PairRays& r, CandLists& cl,
     const bool mine = (mA >= r.thrA) | (mB >= r.thrB);
     if (__any(mine)) {
         CASTER_STAT(12);
-        if (__any(cl.cnt >= kListCap)) drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        if (__any(cl.cnt >= kListCap)) drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB, tm);
         // the sign bits of key - threshold, first key in bit 7; a clear bit is a candidate
         unsigned int neg = push_sign(0u, k0.x - r.thrA);
         neg = push_sign(neg, k0.y - r.thrB);
@@ -462,18 +458,19 @@ CDEV void process_group(const Group& g, int k, const PairRays& r, CandLists& cl,
 // readable.  Two register sets alternate: while one group is evaluated the
 // next one is already on its way from LDS.
 CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, CandLists& cl,
-                     const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB)
+                     const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
+                     WaveTimers& tm)
 {
     filter_ptr src = (filter_ptr)(lds.filter + base);
     Group ga = load_group(src, 0);
 #pragma unroll 1
     for (int k = 0; k < cnt; k += 2 * kGroup) {
         const Group gb = load_group(src, k + kGroup);
-        process_group(ga, k, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        process_group(ga, k, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB, tm);
         ga = load_group(src, k + 2 * kGroup);
-        process_group(gb, k + kGroup, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+        process_group(gb, k + kGroup, r, cl, lds, base, sa, sb, closestA, closestB, bestA, bestB, tm);
     }
-    drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB);
+    drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB, tm);
 }
 
 // The spheres that are candidates for every ray (SceneDev::n_always of them) do not go through
@@ -605,7 +602,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists [kWaves][kListCap][64] (u16),
-    // then the two sphere images
+    // the exact sphere image of one tile, the noise tables
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
     unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * kAccStride);
     float4* s_exact = reinterpret_cast<float4*>(s_dyn + kLdsFixedBytes);
@@ -645,24 +642,9 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     CandLists cl;
     cl.mem = s_cand + wave * kListCap * 64 + lane;
     cl.cnt = 0;
-#ifdef CASTER_TIMERS
-    cl.ticks = 0;
-#endif
-    CASTER_TIME_DECL(t_sched);
-    CASTER_TIME_DECL(t_bounce);
-    CASTER_TIME_DECL(t_refill);
-    CASTER_TIME_DECL(t_isect);
-    CASTER_TIME_DECL(t_total);
-    CASTER_TIME_DECL(n_trips);
-    CASTER_TIME_DECL(n_units_done);
-    CASTER_TIME_DECL(t_last_fetch);
-    CASTER_TIME_DECL(last_unit);
-    CASTER_TIME_DECL(t_empty);
-    CASTER_TIME_DECL(trips_at_empty);
-    CASTER_TIC(tt0);
-#ifdef CASTER_TIMERS
-    const unsigned long long wall0 = wall_clock64();     // 100 MHz
-#endif
+    WaveTimers tm;
+    tm.start();
+    const unsigned long long t_begin = tm.now();
 
     unsigned int trip = 0;
     const unsigned int age = blockIdx.x * (unsigned)CASTER_BLOCKS_PER_CU / gridDim.x;       // blocks are placed in launch order, four per CU
@@ -677,7 +659,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     bool queue_empty = false;
 
     for (;;) {
-        CASTER_TIC(ts0);
+        const unsigned long long t_sched = tm.now();
         if (cur.chunk >= 0 && cur.next >= cur.total) {
             flush_unit(cur, wave_acc, a, lane);
             cur.chunk = -1;
@@ -686,24 +668,20 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         if (cur.chunk < 0 && !queue_empty) {
             cur = fetch_unit(a, tiles_x, n_tiles, lane);
             queue_empty = cur.chunk < 0;
-#ifdef CASTER_TIMERS
-            n_units_done += queue_empty ? 0 : 1;
-            if (queue_empty) { t_empty = wall_clock64(); trips_at_empty = n_trips; }
-            else { t_last_fetch = wall_clock64(); last_unit = (unsigned long long)cur.chunk * 1000000ull + (cur.tg.y0 / 8) * 1000 + cur.tg.x0 / 8; }
-#endif
+            tm.fetched(!queue_empty, cur.chunk, cur.tg.x0 / kTileW, cur.tg.y0 / kTileH);
         }
-        CASTER_TOC(ts0, t_sched);
+        tm.add(WaveTimers::kSchedule, t_sched);
 
         // One copy of the per-slot code serves both slots (the slots trade places
         // after each turn), so a path computes the same values in either slot.
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {
-            CASTER_TIC(tb0);
+            const unsigned long long t_bounce = tm.now();
             bounce(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
-            CASTER_TOC(tb0, t_bounce);
-            CASTER_TIC(tr0);
+            tm.add(WaveTimers::kBounce, t_bounce);
+            const unsigned long long t_refill = tm.now();
             refill(sa, cur, a, cam);
-            CASTER_TOC(tr0, t_refill);
+            tm.add(WaveTimers::kRefill, t_refill);
             swap_slots(sa, sb);
             float tf = closestA; closestA = closestB; closestB = tf;
             int ti = bestA; bestA = bestB; bestB = ti;
@@ -733,16 +711,14 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         default: __builtin_amdgcn_s_setprio(3); break;
         }
         CASTER_STAT(0);
-#ifdef CASTER_TIMERS
-        n_trips += 1;
-#endif
-        CASTER_TIC(ti0);
+        tm.trip();
+        const unsigned long long t_isect = tm.now();
         const PairRays pr = pack_rays(sa, sb, ref);
         closestA = sa.tmax; closestB = sb.tmax;     // a root equal to tmax is still accepted
         bestA = bestB = -1;
         test_always(sc, sa, sb, closestA, closestB, bestA, bestB);
         if (!TILED) {
-            isect_tile(lds, n_lds, 0, pr, cl, sa, sb, closestA, closestB, bestA, bestB);
+            isect_tile(lds, n_lds, 0, pr, cl, sa, sb, closestA, closestB, bestA, bestB, tm);
         } else {
             for (int base = 0; base < sc.n_sph; base += kSphTile) {
                 const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
@@ -750,46 +726,22 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
                 const int padded = stage_spheres(s_exact, sc, base, cnt);
                 lds.count = cnt;
                 __syncthreads();
-                isect_tile(lds, padded, base, pr, cl, sa, sb, closestA, closestB, bestA, bestB);
+                isect_tile(lds, padded, base, pr, cl, sa, sb, closestA, closestB, bestA, bestB, tm);
             }
         }
         non_finite_rule(pr.finiteA, sc.n_sph, closestA, bestA);
         non_finite_rule(pr.finiteB, sc.n_sph, closestB, bestB);
-        CASTER_TOC(ti0, t_isect);
+        tm.add(WaveTimers::kIntersect, t_isect);
     }
-    CASTER_TOC(tt0, t_total);
-    CASTER_TIME_OUT(t_sched, 0);
-    CASTER_TIME_OUT(t_bounce, 1);
-    CASTER_TIME_OUT(t_refill, 2);
-    CASTER_TIME_OUT(t_isect, 3);
-    CASTER_TIME_OUT(t_total, 4);
-#ifdef CASTER_TIMERS
-    CASTER_TIME_OUT(cl.ticks, 5);
-    CASTER_TIME_OUT(wall_clock64() - wall0, 6);
-    if (lane == 0 && blockIdx.x < 1024) {
-        unsigned long long* wl = g_caster_wavelog + (blockIdx.x * 4 + wave) * 16;
-        wl[8] = t_bounce; wl[9] = t_refill; wl[10] = t_isect; wl[11] = cl.ticks; wl[12] = t_total; wl[13] = 0;
-        wl[0] = wall0; wl[1] = wall_clock64(); wl[2] = n_units_done; wl[3] = n_trips;
-        wl[4] = t_last_fetch; wl[5] = last_unit; wl[6] = t_empty; wl[7] = trips_at_empty;
-    }
-#ifndef CASTER_STATS
-    CASTER_TIME_OUT(n_trips, -16);
-#endif
-#endif
+    tm.add(WaveTimers::kTotal, t_begin);
 
-#ifdef CASTER_TIMERS
-    {
-        unsigned int wr = rays;
-        for (int off = 32; off > 0; off >>= 1) wr += __shfl_down(wr, off, 64);
-        if (lane == 0 && blockIdx.x < 1024) g_caster_wavelog[(blockIdx.x * 4 + wave) * 16 + 13] = wr;
-    }
-#endif
     unsigned int wrays = rays;
     for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
     if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
+    tm.report(wave, __shfl(wrays, 0, 64));
 }
 
-// LDS bytes of a render launch: accumulators + both sphere images of one tile.
+// Sphere slots of the exact image in LDS: one tile, padded, plus the read-ahead slack.
 static inline int lds_sphere_slots(int n_sph)
 {
     const int tile = n_sph < kSphTile ? n_sph : kSphTile;
@@ -856,9 +808,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
     CandLists cl;
     cl.mem = s_cand + (threadIdx.x >> 6) * kListCap * 64 + (threadIdx.x & 63);
     cl.cnt = 0;
-#ifdef CASTER_TIMERS
-    cl.ticks = 0;
-#endif
+    WaveTimers tm;
     test_always(sc, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
     for (int base = 0; base < sc.n_sph; base += kSphTile) {
         const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
@@ -866,7 +816,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
         const int padded = stage_spheres(s_exact, sc, base, cnt);
         lds.count = cnt;
         __syncthreads();
-        isect_tile(lds, padded, base, pr, cl, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
+        isect_tile(lds, padded, base, pr, cl, sl[0], sl[1], closest[0], closest[1], best[0], best[1], tm);
     }
     non_finite_rule(pr.finiteA, sc.n_sph, closest[0], best[0]);
     non_finite_rule(pr.finiteB, sc.n_sph, closest[1], best[1]);
