@@ -6,10 +6,11 @@
 //   * a work unit is an 8x8 pixel tile times a chunk of the sample range.  The
 //     grid is persistent: every wave pulls units from a queue (one atomic add
 //     per unit) until it is empty; a 256-thread block holds four waves that
-//     share one copy of the sphere list in LDS;
+//     share one copy of the sphere list in LDS (the operands of the exact test);
 //   * every lane carries TWO path slots, so a wave traces 128 rays per loop
 //     trip and the sphere test runs on packed FP32 (v_pk_*_f32: slot A in the
-//     low half, slot B in the high half), one LDS broadcast read per sphere;
+//     low half, slot B in the high half) with the sphere's numbers as scalar
+//     operands, loaded through the scalar cache;
 //   * when a path ends, its radiance is added to the accumulator of the wave's
 //     current tile in LDS and the slot takes the next (pixel, sample) of the
 //     unit's pool: the finished slots are found with a ballot and numbered with
@@ -40,7 +41,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWaves = kBlock / 64;
-constexpr int kSphTile = 512;               // spheres staged in LDS at a time (two 8 KiB images)
+constexpr int kSphTile = 512;               // spheres per tile: their exact image (8 KiB) is staged in LDS
 constexpr int kListCap = 16;                // candidate list entries per lane (u16 each) before the lists are worked off
 constexpr int kTileW = 8, kTileH = 8;       // pixels per work unit
 
@@ -106,7 +107,7 @@ struct Unit {
 
 constexpr int kAccStride = kTileW * kTileH * 3;     // one accumulator set: 64 pixels x RGB
 typedef unsigned long long acc_t;                   // fixed point, 32 fractional bits
-// LDS in front of the sphere images: accumulators, candidate lists
+// LDS in front of the sphere image: accumulators, candidate lists
 constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * kAccStride + 2 * kWaves * kListCap * 64;
 
 // Pulls the next unit off the queue.  Units are numbered chunk-major.
@@ -453,10 +454,10 @@ CDEV void process_group(const Group& g, int k, const PairRays& r, CandLists& cl,
     }
 }
 
-// Sphere loop over one LDS tile for the two slots of a lane.  cnt is a
-// multiple of 2*kGroup (the tile is padded) and kLdsSlack entries beyond it are
-// readable.  Two register sets alternate: while one group is evaluated the
-// next one is already on its way from LDS.
+// Sphere loop over one tile for the two slots of a lane.  cnt is a multiple of
+// 2*kGroup (the tables are padded) and kLdsSlack entries beyond it are readable.
+// Two register sets alternate: while one group is evaluated the next one is
+// already on its way from the scalar cache.
 CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, CandLists& cl,
                      const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
                      WaveTimers& tm)
