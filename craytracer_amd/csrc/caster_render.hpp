@@ -647,7 +647,6 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     tm.start();
     const unsigned long long t_begin = tm.now();
 
-    unsigned int trip = 0;
     const unsigned int age = blockIdx.x * (unsigned)CASTER_BLOCKS_PER_CU / gridDim.x;       // blocks are placed in launch order, four per CU
     // The unit that feeds the slots.  When its pool is empty its sums so far go to the frame buffer
     // and the wave starts on the next unit at once; the paths still in flight then belong to a tile
@@ -704,8 +703,11 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
 
         // The SIMD issues from its oldest wave first, and these waves hardly ever stall: left alone,
         // the youngest of the four waves on a SIMD runs several times slower than the oldest and
-        // its units finish last.  The issue priority goes round instead.
-        switch ((trip++ + age) & 3u) {
+        // its units finish last.  The issue priority goes round instead, by the clock (a turn is
+        // 2^20 cycles, a few trips) so that the four waves of a SIMD, which differ in age, hold
+        // four different levels at any time.  (Going round by the trip count left ties, which the
+        // hardware again breaks by age: the youngest wave still ran 1.7 times slower.)
+        switch (((unsigned int)(__builtin_readcyclecounter() >> 20) + age) & 3u) {
         case 0: __builtin_amdgcn_s_setprio(0); break;
         case 1: __builtin_amdgcn_s_setprio(1); break;
         case 2: __builtin_amdgcn_s_setprio(2); break;
