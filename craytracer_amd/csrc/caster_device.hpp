@@ -121,8 +121,6 @@ struct SceneView {
     const Mat*    mats;
     const Img*    imgs;
     int n_sph, n_rect, n_mat, n_img;
-    int n_always;
-    int always[4];          // spheres tested directly for every ray
     // Perlin tables, staged in LDS by every kernel that evaluates textures (stage_noise).  An LDS
     // address may be 0, which is also the null value of that address space: has_noise says
     // whether the tables are there.

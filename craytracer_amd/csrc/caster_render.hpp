@@ -475,13 +475,29 @@ CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, 
 }
 
 // The spheres that are candidates for every ray (SceneDev::n_always of them) do not go through
-// the lists: each lane tests them for its two slots directly.
-CDEV void test_always(const SceneView& sc, const Slot& sa, const Slot& sb, float& closestA, float& closestB,
-                      int& bestA, int& bestB)
+// the lists: each lane tests them for its two slots directly.  Their exact images and list
+// positions sit in LDS (stage_always).
+struct AlwaysLds {
+    float4 exact[kMaxAlways];
+    int index[kMaxAlways];
+};
+
+CDEV void stage_always(AlwaysLds* al, const SceneDev& sd)
 {
-    for (int h = 0; h < sc.n_always; ++h) {
-        const int index = sc.always[h];
-        const float4 e = exact_image(sc.sph[index]);
+    if (threadIdx.x < kMaxAlways) {
+        const int k = (int)threadIdx.x;
+        const bool used = k < sd.n_always;
+        al->index[k] = used ? sd.always[k] : 0;
+        al->exact[k] = used ? exact_image(sd.sph[sd.always[k]]) : exact_pad();
+    }
+}
+
+CDEV void test_always(const AlwaysLds* al, int n_always, const Slot& sa, const Slot& sb, float& closestA,
+                      float& closestB, int& bestA, int& bestB)
+{
+    for (int h = 0; h < n_always; ++h) {
+        const int index = al->index[h];
+        const float4 e = al->exact[h];
         float t;
         if (candidate_root(e, sa.o, sa.d, sa.aa, sa.tmin, t)) take_hit(t, index, closestA, bestA);
         if (candidate_root(e, sb.o, sb.d, sb.aa, sb.tmin, t)) take_hit(t, index, closestB, bestB);
@@ -602,6 +618,7 @@ __global__ __launch_bounds__(kBlock, CASTER_BLOCKS_PER_CU)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
     extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ AlwaysLds s_always;
     // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists [kWaves][kListCap][64] (u16),
     // the exact sphere image of one tile, the noise tables
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
@@ -620,6 +637,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
 
     acc_t* wave_acc = s_acc + wave * kAccStride;
     for (int k = lane; k < kAccStride; k += 64) wave_acc[k] = 0;
+    stage_always(&s_always, a.scene);
     int n_lds = 0;
     if (!TILED) n_lds = stage_spheres(s_exact, sc, 0, sc.n_sph);
     SphereLds lds;
@@ -719,7 +737,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         const PairRays pr = pack_rays(sa, sb, ref);
         closestA = sa.tmax; closestB = sb.tmax;     // a root equal to tmax is still accepted
         bestA = bestB = -1;
-        test_always(sc, sa, sb, closestA, closestB, bestA, bestB);
+        test_always(&s_always, a.scene.n_always, sa, sb, closestA, closestB, bestA, bestB);
         if (!TILED) {
             isect_tile(lds, n_lds, 0, pr, cl, sa, sb, closestA, closestB, bestA, bestB, tm);
         } else {
@@ -780,6 +798,9 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
 {
     __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
     __shared__ unsigned short s_cand[kWaves * kListCap * 64];
+    __shared__ AlwaysLds s_always;
+    stage_always(&s_always, sd);
+    __syncthreads();
     const SceneView sc = view_of(sd);
     SphereLds lds;
     lds.exact = s_exact;
@@ -812,7 +833,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
     cl.mem = s_cand + (threadIdx.x >> 6) * kListCap * 64 + (threadIdx.x & 63);
     cl.cnt = 0;
     WaveTimers tm;
-    test_always(sc, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
+    test_always(&s_always, sd.n_always, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
     for (int base = 0; base < sc.n_sph; base += kSphTile) {
         const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
         __syncthreads();
