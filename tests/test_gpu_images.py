@@ -96,6 +96,28 @@ def test_fast_mode_is_scheduling_independent(gpu, ca):
     gpu.set_chunk(0)
 
 
+def test_chunk_plan_and_tiled_scene_are_scheduling_independent(gpu, ca):
+    """The library's own chunk plan (large chunks first, small ones at the end) against equal chunks,
+    on a scene large enough to stream through LDS in tiles and with more samples than one chunk
+    holds: sums are integers, so every split gives the same bits in strict mode too."""
+    fs = ca.scene_stress(700, 4)
+    gpu.upload_scene(fs)
+    w, h, spp, depth, seed = 61, 35, 150, 50, 5
+    cam = ca.default_camera(w / h)
+    ref, ref_rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
+    for chunk in (3, 16, 150):
+        gpu.set_chunk(chunk)
+        s, rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
+        assert rays == ref_rays and np.array_equal(s, ref)
+    gpu.set_chunk(0)
+    # a sample count far beyond the chunk table's comfortable range, few pixels
+    a, ra, _ = gpu.render_image(cam, 9, 5, 20000, 6, seed, strict=False)
+    gpu.set_chunk(64)
+    b, rb, _ = gpu.render_image(cam, 9, 5, 20000, 6, seed, strict=False)
+    gpu.set_chunk(0)
+    assert ra == rb and np.array_equal(a, b)
+
+
 def test_sample_partitions_sum_to_the_frame(gpu, orc, ca):
     """Per-GPU sample partitions [g*spp/G, (g+1)*spp/G): same paths, sums add up."""
     fs = ca.scene_rtiow(1)
