@@ -1,4 +1,5 @@
-"""Developer check: strict-mode frames at benchmark size against the CPU restatement (same random
+"""Not collected by pytest (run it by name on a GPU box: python tests/big_frame_check.py).
+Developer check: strict-mode frames at benchmark size against the CPU restatement (same random
 streams): ray counts must be equal and every channel sum within 1e-4 relative."""
 import os
 import sys
