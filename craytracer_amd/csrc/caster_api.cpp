@@ -425,7 +425,7 @@ static int plan_chunks(const caster_hip_ctx* ctx, int width, int height, int sam
     int left = sample_count;
     while (left > 0) {
         int c = (int)((double)left * share);
-        if (c > 64 && min_chunk <= 64) c = 64;
+        if (c > (min_chunk > 64 ? min_chunk : 64)) c = min_chunk > 64 ? min_chunk : 64;
         if (c < min_chunk) c = min_chunk;
         if (c > left || n == cap - 1) c = left;
         start[n + 1] = start[n] + c;
