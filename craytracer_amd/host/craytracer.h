@@ -128,6 +128,8 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd);
 void ray_dispatcher_set_seed(ray_dispatcher* rd, u32 seed);
 void ray_dispatcher_set_strict(ray_dispatcher* rd, int strict);
 void ray_dispatcher_set_batch(ray_dispatcher* rd, i32 samples_per_batch);
+/* More jobs than devices (job g on device g % devices, own context and sample range each). */
+void ray_dispatcher_set_jobs(ray_dispatcher* rd, i32 jobs);
 
 /* ---- scenes ---------------------------------------------------------- */
 /* A scene owns its spheres, rects, materials and textures; world lists them. */

@@ -28,6 +28,7 @@ typedef struct {
 
 typedef struct {
     int n_jobs;
+    int n_dev;
     int started;
     pthread_t threads[MAX_THREADS];
     gpu_job jobs[MAX_THREADS];
@@ -147,6 +148,7 @@ ray_dispatcher new_ray_dispatcher(u8 num_threads, u8 blocks, i32 width, i32 heig
     d.image = img;
     if (be) {
         be->n_jobs = n_jobs;
+        be->n_dev = n_dev > 0 ? n_dev : 1;
         be->seed = 0xC0FFEEu;
         be->strict = 0;
         be->batch = 0;
@@ -165,6 +167,20 @@ void ray_dispatcher_set_seed(ray_dispatcher* rd, u32 seed) { if (rd->backend) ((
 void ray_dispatcher_set_strict(ray_dispatcher* rd, int strict) { if (rd->backend) ((gpu_backend*)rd->backend)->strict = strict; }
 void ray_dispatcher_set_batch(ray_dispatcher* rd, i32 n) { if (rd->backend) ((gpu_backend*)rd->backend)->batch = n; }
 
+/* More jobs than devices: job g runs on device g % devices, each with its own context and sample
+ * range.  new_ray_dispatcher() never does this by itself. */
+void ray_dispatcher_set_jobs(ray_dispatcher* rd, i32 jobs)
+{
+    gpu_backend* be = (gpu_backend*)rd->backend;
+    if (!be || be->started || rd->status) return;
+    if (jobs < 1) jobs = 1;
+    if (jobs > MAX_THREADS) jobs = MAX_THREADS;
+    if (rd->spp > 0 && jobs > rd->spp) jobs = rd->spp;
+    be->n_jobs = jobs;
+    rd->thread_count = (u8)jobs;
+    rd->block_size = (rd->spp + jobs - 1) / jobs;
+}
+
 void ray_dispatcher_run_jobs(ray_dispatcher* rd)
 {
     gpu_backend* be = (gpu_backend*)rd->backend;
@@ -176,7 +192,7 @@ void ray_dispatcher_run_jobs(ray_dispatcher* rd)
         memset(job, 0, sizeof *job);
         job->rd = rd;
         job->id = g;
-        job->device = g;
+        job->device = g % be->n_dev;
         job->s_begin = (int)(((long long)rd->spp * g) / G);
         job->s_count = (int)(((long long)rd->spp * (g + 1)) / G) - job->s_begin;
         if (pthread_create(&be->threads[g], NULL, job_main, job) != 0) {

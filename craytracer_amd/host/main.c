@@ -3,7 +3,7 @@
  * same camera, same output file; the preview window is left out.
  *
  *   craytracer <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|perlin|stress:N]
- *              [--seed S] [--strict] [--batch B] [--texture file.bmp] [--out file.bmp]
+ *              [--seed S] [--strict] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp]
  */
 #include "craytracer.h"
 
@@ -14,7 +14,7 @@ int main(int argc, char* argv[])
 {
     if (argc < 5) {
         fprintf(stderr, "usage: %s <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|perlin|stress:N] [--seed S] "
-                        "[--strict] [--batch B] [--texture file.bmp] [--out file.bmp]\n", argv[0]);
+                        "[--strict] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp]\n", argv[0]);
         return 2;
     }
     const f32 aspect = 16.0f / 9.0f;                 /* src/main.c:64-68 */
@@ -29,12 +29,13 @@ int main(int argc, char* argv[])
     const char* texture_name = NULL;
     u32 seed = 0xC0FFEEu;
     int strict = 0;
-    i32 batch = 0;
+    i32 batch = 0, jobs = 0;
     for (int k = 5; k < argc; k++) {
         if (!strcmp(argv[k], "--scene") && k + 1 < argc) scene_name = argv[++k];
         else if (!strcmp(argv[k], "--seed") && k + 1 < argc) seed = (u32)strtoul(argv[++k], NULL, 0);
         else if (!strcmp(argv[k], "--strict")) strict = 1;
         else if (!strcmp(argv[k], "--batch") && k + 1 < argc) batch = atoi(argv[++k]);
+        else if (!strcmp(argv[k], "--jobs") && k + 1 < argc) jobs = atoi(argv[++k]);
         else if (!strcmp(argv[k], "--texture") && k + 1 < argc) texture_name = argv[++k];
         else if (!strcmp(argv[k], "--out") && k + 1 < argc) out_name = argv[++k];
         else { fprintf(stderr, "unknown argument: %s\n", argv[k]); return 2; }
@@ -68,6 +69,7 @@ int main(int argc, char* argv[])
     ray_dispatcher_set_seed(&dispatcher, seed);
     ray_dispatcher_set_strict(&dispatcher, strict);
     ray_dispatcher_set_batch(&dispatcher, batch);
+    if (jobs > 0) ray_dispatcher_set_jobs(&dispatcher, jobs);      /* more jobs than GPUs: they share the devices */
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -37,3 +37,23 @@ def test_cli_output_matches_restatement(tmp_path, ca, orc, scene, make):
     assert (np.abs(got_px.astype(int) - want_px.astype(int)) <= 1).all()
     assert (got_px == want_px).mean() > 0.999
     assert f"Rays: {rays} " in p.stdout
+
+
+def test_cli_three_jobs_on_one_gpu_sum_to_the_same_frame(tmp_path, ca, orc):
+    """The dispatcher's multi-GPU leg (one host thread, context and sample range per job, sums added at
+    the fence) with three jobs sharing the one device of the test box."""
+    exe = os.path.join(os.path.dirname(ca.lib_paths()["host"]), "craytracer")
+    height, spp, depth, seed = 54, 10, 50, 99
+    outs = []
+    for jobs in (1, 3):
+        out = str(tmp_path / f"out{jobs}.bmp")
+        p = subprocess.run([exe, str(height), str(spp), str(depth), "1", "--scene", "rtiow", "--strict", "--seed", str(seed),
+                            "--jobs", str(jobs), "--out", out], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        assert p.stdout.count("Job finished!") == jobs
+        outs.append((open(out, "rb").read(), p.stdout))
+    width = int(np.float32(height) * (np.float32(16.0) / np.float32(9.0)))
+    a, b = _bmp_pixels(outs[0][0], width, height), _bmp_pixels(outs[1][0], width, height)
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a == b).mean() > 0.999     # float sums regrouped per job
+    rays = [int(o[1].split("Rays: ")[1].split()[0]) for o in outs]
+    assert rays[0] == rays[1]
