@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "320", "--height", "180", "--spp", "24",
-                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=300)
+                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -74,6 +74,6 @@ def test_rccl_reduce_follows_the_render_kernel(tmp_path):
     script = tmp_path / "rccl_worker.py"
     script.write_text(_RCCL_WORKER)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    p = subprocess.run([sys.executable, str(script), ROOT, "29517"], capture_output=True, text=True, timeout=300, env=env)
+    p = subprocess.run([sys.executable, str(script), ROOT, "29517"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert "rccl-ok" in p.stdout
