@@ -342,6 +342,13 @@ class CasterHip:
     def synchronize(self):
         _check(self._lib.caster_hip_synchronize(self._ctx), "caster_hip_synchronize")
 
+    def add_from_device(self, dst_ptr: int, src_device: int, src_ptr: int, n_floats: int):
+        """dst += src where src lives on another context's device (its work must be complete)."""
+        _check(
+            self._lib.caster_hip_add_from_device(self._ctx, C.c_void_p(dst_ptr), C.c_int(src_device), C.c_void_p(src_ptr), C.c_size_t(n_floats)),
+            "caster_hip_add_from_device",
+        )
+
     # -- the hot path
     def render(self, cam, width, height, sample_begin, sample_count, max_depth, seed, accum_ptr: int, strict=False):
         cam = _f32(cam, (19,))

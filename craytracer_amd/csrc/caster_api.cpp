@@ -42,6 +42,8 @@ struct caster_hip_ctx {
     // scene
     bool has_scene = false;
     caster::SceneDev scene{};
+    float* staging = nullptr;   // peer-copy target of caster_hip_add_from_device
+    size_t staging_bytes = 0;
     std::vector<void*> scene_allocs;
     bool needs_noise = false;   // the scene has a CASTER_TTYPE_NOISE material
     // scratch
@@ -177,6 +179,7 @@ int caster_hip_destroy(caster_hip_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     if (ctx->fixed) (void)hipFree(ctx->fixed);
+    if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->rays_dev) (void)hipFree(ctx->rays_dev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -486,6 +489,28 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(caster::launch_fold(ctx->fixed, (int)n_pixels, sample_count, reinterpret_cast<float4*>(accum_dev),
                                 ctx->stream));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_add_from_device(caster_hip_ctx* ctx, float* dst_dev, int src_device, const float* src_dev, size_t n_floats)
+{
+    if (!ctx || !dst_dev || !src_dev) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || src_device < 0 || src_device >= n_dev)
+        return fail(CASTER_HIP_ERR_ARG, "source device %d out of range", src_device);
+    if (n_floats == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    const size_t bytes = n_floats * sizeof(float);
+    if (bytes > ctx->staging_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->staging) HIP_TRY(hipFree(ctx->staging));
+        ctx->staging = nullptr;
+        ctx->staging_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->staging), bytes));
+        ctx->staging_bytes = bytes;
+    }
+    HIP_TRY(hipMemcpyPeerAsync(ctx->staging, ctx->device, src_dev, src_device, bytes, ctx->stream));
+    HIP_TRY(caster::launch_add(dst_dev, ctx->staging, n_floats, ctx->stream));
     return CASTER_HIP_OK;
 }
 

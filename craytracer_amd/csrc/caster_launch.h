@@ -90,6 +90,7 @@ CASTER_DECLARE_LAUNCHERS(fast)
 
 // Mode-independent kernels (defined in the strict unit).
 hipError_t launch_fold(const unsigned long long* fixed, int n_pixels, int sample_count, float4* accum, hipStream_t st);
+hipError_t launch_add(float* dst, const float* src, size_t n, hipStream_t st);
 hipError_t launch_resolve(const float4* accum, int width, int height, int spp, uint8_t* rgba, hipStream_t st);
 hipError_t launch_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24, hipStream_t st);
 

@@ -22,6 +22,13 @@ __global__ void k_fold(const unsigned long long* fixed, int n_pixels, int sample
     accum[p] = acc;
 }
 
+// dst[i] += src[i]: the sum of two GPUs' sample partitions (HBM bound: 12 bytes per float).
+__global__ void k_add(float* dst, const float* src, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = dst[i] + src[i];
+}
+
 // src/dispatcher.c:11,29-34 and src/image.c:30-36.
 __global__ void k_resolve(const float4* accum, int width, int height, int spp, uint8_t* rgba)
 {
@@ -52,6 +59,15 @@ hipError_t launch_fold(const unsigned long long* fixed, int n_pixels, int sample
 {
     hipLaunchKernelGGL(k_fold, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, st, fixed, n_pixels,
                        sample_count, accum);
+    return hipGetLastError();
+}
+
+hipError_t launch_add(float* dst, const float* src, size_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(k_add, dim3((unsigned)blocks), dim3(256), 0, st, dst, src, n);
     return hipGetLastError();
 }
 

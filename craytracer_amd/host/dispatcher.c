@@ -20,7 +20,6 @@ typedef struct {
     int s_begin, s_count;
     caster_hip_ctx* ctx;
     float* accum_dev;
-    float* accum_host;
     int samples_done;
     int status;
     char err[256];
@@ -104,9 +103,8 @@ static void* job_main(void* arg)
         }
     }
 
-    job->accum_host = (float*)malloc(accum_bytes);
-    if (!job->accum_host) { job->status = CASTER_HIP_ERR_ARG; goto done; }
-    if ((rc = caster_hip_download(job->ctx, job->accum_host, job->accum_dev, accum_bytes))) job_fail(job, rc);
+    /* the sums stay on the device; the fence adds them GPU to GPU once every job's work is complete */
+    if ((rc = caster_hip_synchronize(job->ctx))) job_fail(job, rc);
 
 done:
     printf("Thread #%d: Job finished!\n", id);                       /* src/dispatcher.c:50 */
@@ -215,22 +213,12 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
     if (!rd->status && be->n_jobs > 0) {
         gpu_job* root = &be->jobs[0];
         int done = root->samples_done;
-        /* radiance sums are linear: add them before the scale and the gamma (src/dispatcher.c:29-30) */
-        for (int g = 1; g < be->n_jobs; g++) {
-            const float* src = be->jobs[g].accum_host;
-            float* dst = root->accum_host;
-            for (size_t k = 0; k < n_px * 4; k++) dst[k] += src[k];
-            done += be->jobs[g].samples_done;
-        }
+        /* radiance sums are linear: add them before the scale and the gamma (src/dispatcher.c:29-30).
+         * Job 0's GPU pulls the other GPUs' sums over the peer links, in job order. */
         int rc = 0;
-        if (be->n_jobs > 1) {
-            /* upload the combined sums to job 0's GPU for the resolve */
-            float* tmp = NULL;
-            rc = caster_hip_free(root->ctx, root->accum_dev);
-            root->accum_dev = NULL;
-            if (!rc) rc = caster_hip_malloc(root->ctx, n_px * 16, (void**)&tmp);
-            root->accum_dev = tmp;
-            if (!rc) rc = caster_hip_upload(root->ctx, root->accum_dev, root->accum_host, n_px * 16);
+        for (int g = 1; g < be->n_jobs && !rc; g++) {
+            rc = caster_hip_add_from_device(root->ctx, root->accum_dev, be->jobs[g].device, be->jobs[g].accum_dev, n_px * 4);
+            done += be->jobs[g].samples_done;
         }
         if (!rc && done > 0 && rd->image && rd->image->data)
             rc = caster_hip_resolve(root->ctx, root->accum_dev, rd->block_width, rd->block_height, done, rd->image->data);
@@ -242,7 +230,6 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
             if (job->accum_dev) caster_hip_free(job->ctx, job->accum_dev);
             caster_hip_destroy(job->ctx);
         }
-        free(job->accum_host);
         memset(job, 0, sizeof *job);
     }
     be->started = 0;

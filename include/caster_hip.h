@@ -128,6 +128,14 @@ int caster_hip_download(caster_hip_ctx* ctx, void* host_dst, const void* dev_src
 int caster_hip_upload(caster_hip_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 int caster_hip_synchronize(caster_hip_ctx* ctx);
 
+/* dst_dev[i] += src_dev[i] for n_floats floats, where src_dev lives on device src_device (memory
+ * of another context, whose work on it has completed) and dst_dev on ctx's device: a peer-to-peer
+ * copy (xGMI between the GPUs of a node) into a staging buffer, then one add kernel.  This is the
+ * sum of the per-GPU sample partitions; the reference has no counterpart, its threads write
+ * disjoint row blocks (src/dispatcher.c:12).  Adding the partitions in a fixed order gives
+ * reproducible sums. */
+int caster_hip_add_from_device(caster_hip_ctx* ctx, float* dst_dev, int src_device, const float* src_dev, size_t n_floats);
+
 /*
  * The sample loop of job_func (src/dispatcher.c:12-27) for every pixel and the
  * samples [sample_begin, sample_begin + sample_count): linear RGB sums are

@@ -138,6 +138,42 @@ def test_sample_partitions_sum_to_the_frame(gpu, orc, ca):
         assert np.array_equal(acc[..., 3], whole[..., 3])
 
 
+def test_device_side_sum_of_two_contexts(gpu, ca):
+    """Two contexts render halves of the sample range into their own buffers; the first pulls the
+    second's sums across (a peer copy between GPUs of a node, a plain copy on one) and adds them on
+    the device: the same bits as adding the downloaded halves, at several sizes in a row."""
+    fs = ca.scene_0()
+    other = ca.CasterHip(0)
+    try:
+        gpu.upload_scene(fs)
+        other.upload_scene(fs)
+        for (w, h, spp) in ((64, 36, 8), (33, 17, 5), (70, 40, 6)):
+            cam = ca.default_camera(w / h)
+            nb = w * h * 16
+            a, b = gpu.malloc(nb), other.malloc(nb)
+            try:
+                gpu.memset_zero(a, nb)
+                other.memset_zero(b, nb)
+                half = spp // 2
+                gpu.render(cam, w, h, 0, half, 50, 7, a, strict=True)
+                other.render(cam, w, h, half, spp - half, 50, 7, b, strict=True)
+                gpu.synchronize()
+                other.synchronize()
+                ha = gpu.download(a, (h, w, 4), np.float32)
+                hb = other.download(b, (h, w, 4), np.float32)
+                gpu.add_from_device(a, 0, b, w * h * 4)
+                total = gpu.download(a, (h, w, 4), np.float32)
+            finally:
+                gpu.free(a)
+                other.free(b)
+            assert np.array_equal(total, ha + hb)
+            assert np.all(total[..., 3] == spp)
+        with pytest.raises(ca.CasterHipError):
+            gpu.add_from_device(1, 99, 1, 4)
+    finally:
+        other.close()
+
+
 def test_empty_and_degenerate_inputs(gpu, ca):
     fs = ca.scene_0()
     gpu.upload_scene(fs)
