@@ -131,6 +131,34 @@ void ray_dispatcher_set_batch(ray_dispatcher* rd, i32 samples_per_batch);
 /* More jobs than devices (job g on device g % devices, own context and sample range each). */
 void ray_dispatcher_set_jobs(ray_dispatcher* rd, i32 jobs);
 
+/* Progressive accumulation across runs (the reference plans a "gradual image add mode",
+ * src/dispatcher.c:6-7).  set_checkpoint: the fence writes the frame's radiance sums and the sample
+ * ranges they hold to the file, also after a cancel.  resume: the sums of the file become the start
+ * of the frame and the jobs render only the samples of [0, spp) that it lacks; returns 0, or -1 if
+ * the file is unreadable or belongs to another frame size, seed, arithmetic mode, depth or scene.
+ * Call both before run_jobs. */
+void ray_dispatcher_set_checkpoint(ray_dispatcher* rd, const char* path);
+int ray_dispatcher_resume(ray_dispatcher* rd, const char* path);
+
+/* Sample ranges and the checkpoint file. */
+#define CRT_MAX_RANGES 256
+typedef struct { i32 begin, count; } crt_range;
+typedef struct {
+    u32 width, height, seed;
+    i32 strict, max_depth;
+    u64 scene_hash;
+    i32 n_ranges;
+    crt_range ranges[CRT_MAX_RANGES];
+    f32* sums;                   /* width * height * 4, owned */
+} crt_checkpoint;
+int crt_ranges_normalize(crt_range* r, int n);
+i32 crt_ranges_total(const crt_range* r, int n);
+int crt_ranges_complement(const crt_range* done, int n_done, i32 spp, crt_range* out, int cap);
+int crt_ranges_slice(const crt_range* r, int n, i32 first, i32 count, crt_range* out, int cap);
+int crt_checkpoint_write(const char* path, const crt_checkpoint* cp);
+crt_checkpoint* crt_checkpoint_read(const char* path);
+void crt_checkpoint_free(crt_checkpoint* cp);
+
 /* ---- scenes ---------------------------------------------------------- */
 /* A scene owns its spheres, rects, materials and textures; world lists them. */
 typedef struct {
@@ -170,6 +198,7 @@ const void* crt_flat_objects(const crt_flat_scene* fs);    /* caster_object[]   
 const void* crt_flat_materials(const crt_flat_scene* fs);  /* caster_material[] */
 const void* crt_flat_images(const crt_flat_scene* fs);     /* caster_image[]    */
 const void* crt_flat_noise(const crt_flat_scene* fs);      /* caster_noise* or NULL */
+u64 crt_flat_hash(const crt_flat_scene* fs);               /* of the object and material tables */
 
 /* Bytes write_img_buffer_to_file() writes, into out (54 + h*stride bytes). */
 long crt_bmp_encode(const img_buffer* buffer, u8* out);

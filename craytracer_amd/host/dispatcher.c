@@ -17,7 +17,9 @@
 typedef struct {
     ray_dispatcher* rd;
     int id, device;
-    int s_begin, s_count;
+    crt_range seg[CRT_MAX_RANGES];   /* the samples this job renders, in order */
+    int n_seg;
+    crt_range done[CRT_MAX_RANGES];  /* what it has rendered (shorter than seg after a cancel) */
     caster_hip_ctx* ctx;
     float* accum_dev;
     int samples_done;
@@ -35,6 +37,8 @@ typedef struct {
     u32 seed;
     int strict;
     i32 batch;
+    crt_checkpoint* resume;          /* sums and sample ranges of an earlier run, or NULL */
+    char* checkpoint_path;           /* where the fence writes the frame's checkpoint, or NULL */
 } gpu_backend;
 
 static u64 now_us(void)
@@ -76,14 +80,23 @@ static void* job_main(void* arg)
         goto done;
     }
 
-    {
-        caster_camera cam;
-        memcpy(&cam, rd->cam, sizeof cam);   /* cam_info and caster_camera share one layout */
-        const i32 batch = be->batch > 0 ? be->batch : job->s_count;
-        for (int s = job->s_begin; s < job->s_begin + job->s_count; s += batch) {
+    /* the first job continues the sums of the run that is resumed */
+    if (id == 0 && be->resume && (rc = caster_hip_upload(job->ctx, job->accum_dev, be->resume->sums, accum_bytes))) {
+        job_fail(job, rc);
+        goto done;
+    }
+
+    caster_camera cam;
+    memcpy(&cam, rd->cam, sizeof cam);   /* cam_info and caster_camera share one layout */
+    for (int k = 0; k < job->n_seg; k++) {
+        const int s_begin = job->seg[k].begin, s_count = job->seg[k].count;
+        const i32 batch = be->batch > 0 ? be->batch : s_count;
+        job->done[k].begin = s_begin;
+        job->done[k].count = 0;
+        for (int s = s_begin; s < s_begin + s_count; s += batch) {
             /* src/dispatcher.c:42-45: stop when the window was closed */
             if (!__atomic_load_n(&rd->atomic_window_running, __ATOMIC_RELAXED)) break;
-            const int cnt = (s + batch <= job->s_begin + job->s_count) ? batch : job->s_begin + job->s_count - s;
+            const int cnt = (s + batch <= s_begin + s_count) ? batch : s_begin + s_count - s;
             const u64 t0 = now_us();
             uint64_t rays = 0;
             if ((rc = caster_hip_render(job->ctx, &cam, rd->block_width, rd->block_height, s, cnt, rd->max_depth,
@@ -94,6 +107,7 @@ static void* job_main(void* arg)
             }
             const u64 us = now_us() - t0;
             job->samples_done += cnt;
+            job->done[k].count += cnt;
             /* src/dispatcher.c:36-40, per batch instead of per pixel */
             __atomic_store_n(&rd->atomic_spp_counter[id], us ? us : 1, __ATOMIC_RELAXED);
             __atomic_fetch_add(&rd->atomic_spp_counter_total[id], us, __ATOMIC_RELAXED);
@@ -185,14 +199,21 @@ void ray_dispatcher_run_jobs(ray_dispatcher* rd)
     if (!be || rd->status || be->started) return;
     be->started = 1;
     const int G = be->n_jobs;
+    /* the samples still to render: all of [0, spp), or what the resumed run lacks */
+    crt_range todo[CRT_MAX_RANGES];
+    const int n_todo = crt_ranges_complement(be->resume ? be->resume->ranges : NULL, be->resume ? be->resume->n_ranges : 0,
+                                             rd->spp, todo, CRT_MAX_RANGES);
+    const long long total = n_todo > 0 ? crt_ranges_total(todo, n_todo) : 0;
     for (int g = 0; g < G; g++) {
         gpu_job* job = &be->jobs[g];
         memset(job, 0, sizeof *job);
         job->rd = rd;
         job->id = g;
         job->device = g % be->n_dev;
-        job->s_begin = (int)(((long long)rd->spp * g) / G);
-        job->s_count = (int)(((long long)rd->spp * (g + 1)) / G) - job->s_begin;
+        const i32 first = (i32)((total * g) / G);
+        const i32 count = (i32)((total * (g + 1)) / G) - first;
+        job->n_seg = n_todo > 0 ? crt_ranges_slice(todo, n_todo, first, count, job->seg, CRT_MAX_RANGES) : 0;
+        if (job->n_seg < 0) job->n_seg = 0;
         if (pthread_create(&be->threads[g], NULL, job_main, job) != 0) {
             job->status = CASTER_HIP_ERR_STATE;
             rd->status = CASTER_HIP_ERR_STATE;
@@ -210,9 +231,20 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
         if (be->jobs[g].rd) pthread_join(be->threads[g], NULL);
         if (be->jobs[g].status && !rd->status) rd->status = be->jobs[g].status;
     }
+    /* the sample ranges the frame now holds */
+    static _Thread_local crt_range held[CRT_MAX_RANGES * 2];
+    int n_held = 0;
+    if (be->resume)
+        for (int k = 0; k < be->resume->n_ranges; k++) held[n_held++] = be->resume->ranges[k];
+    for (int g = 0; g < be->n_jobs; g++) {
+        int m = crt_ranges_normalize(be->jobs[g].done, be->jobs[g].n_seg);
+        if (n_held + m > CRT_MAX_RANGES * 2) n_held = crt_ranges_normalize(held, n_held);
+        for (int k = 0; k < m && n_held < CRT_MAX_RANGES * 2; k++) held[n_held++] = be->jobs[g].done[k];
+    }
+    n_held = crt_ranges_normalize(held, n_held);
     if (!rd->status && be->n_jobs > 0) {
         gpu_job* root = &be->jobs[0];
-        int done = root->samples_done;
+        int done = root->samples_done + (be->resume ? crt_ranges_total(be->resume->ranges, be->resume->n_ranges) : 0);
         /* radiance sums are linear: add them before the scale and the gamma (src/dispatcher.c:29-30).
          * Job 0's GPU pulls the other GPUs' sums over the peer links, in job order. */
         int rc = 0;
@@ -222,6 +254,25 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
         }
         if (!rc && done > 0 && rd->image && rd->image->data)
             rc = caster_hip_resolve(root->ctx, root->accum_dev, rd->block_width, rd->block_height, done, rd->image->data);
+        if (!rc && be->checkpoint_path) {
+            crt_checkpoint cp;
+            memset(&cp, 0, sizeof cp);
+            cp.width = (u32)rd->block_width; cp.height = (u32)rd->block_height;
+            cp.seed = be->seed; cp.strict = be->strict ? 1 : 0; cp.max_depth = rd->max_depth;
+            cp.scene_hash = crt_flat_hash(be->flat);
+            cp.n_ranges = n_held < CRT_MAX_RANGES ? n_held : CRT_MAX_RANGES;
+            memcpy(cp.ranges, held, (size_t)cp.n_ranges * sizeof(crt_range));
+            cp.sums = (f32*)malloc(n_px * 4 * sizeof(f32));
+            if (!cp.sums || n_held > CRT_MAX_RANGES) {
+                fprintf(stderr, "checkpoint %s: not written (out of memory or too many sample ranges)\n", be->checkpoint_path);
+                rd->status = CASTER_HIP_ERR_ARG;
+            } else if ((rc = caster_hip_download(root->ctx, cp.sums, root->accum_dev, n_px * 4 * sizeof(f32))) == 0 &&
+                       crt_checkpoint_write(be->checkpoint_path, &cp) != 0) {
+                fprintf(stderr, "checkpoint %s: write failed\n", be->checkpoint_path);
+                rd->status = CASTER_HIP_ERR_ARG;
+            }
+            free(cp.sums);
+        }
         if (rc) { job_fail(root, rc); rd->status = rc; }
     }
     for (int g = 0; g < be->n_jobs; g++) {
@@ -236,11 +287,39 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
     return clock();
 }
 
+void ray_dispatcher_set_checkpoint(ray_dispatcher* rd, const char* path)
+{
+    gpu_backend* be = (gpu_backend*)rd->backend;
+    if (!be || be->started) return;
+    free(be->checkpoint_path);
+    be->checkpoint_path = path ? strdup(path) : NULL;
+}
+
+int ray_dispatcher_resume(ray_dispatcher* rd, const char* path)
+{
+    gpu_backend* be = (gpu_backend*)rd->backend;
+    if (!be || be->started || rd->status) return -1;
+    crt_checkpoint* cp = crt_checkpoint_read(path);
+    if (!cp) { fprintf(stderr, "resume: cannot read %s\n", path ? path : "(null)"); return -1; }
+    if (cp->width != (u32)rd->block_width || cp->height != (u32)rd->block_height || cp->seed != be->seed ||
+        (cp->strict != 0) != (be->strict != 0) || cp->max_depth != rd->max_depth ||
+        cp->scene_hash != crt_flat_hash(be->flat)) {
+        fprintf(stderr, "resume: %s belongs to another frame (size, seed, arithmetic mode, depth or scene differ)\n", path);
+        crt_checkpoint_free(cp);
+        return -1;
+    }
+    crt_checkpoint_free(be->resume);
+    be->resume = cp;
+    return 0;
+}
+
 void free_ray_dispatcher(ray_dispatcher* rd)
 {
     gpu_backend* be = (gpu_backend*)rd->backend;
     if (!be) return;
     if (be->started) ray_dispatcher_worker_fence(rd);
+    crt_checkpoint_free(be->resume);
+    free(be->checkpoint_path);
     crt_flat_free(be->flat);
     free(be);
     rd->backend = NULL;

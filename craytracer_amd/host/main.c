@@ -4,6 +4,10 @@
  *
  *   craytracer <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|perlin|stress:N]
  *              [--seed S] [--strict] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp]
+ *              [--checkpoint file] [--resume file]
+ *
+ * --checkpoint writes the frame's radiance sums and sample ranges; --resume starts from such a
+ * file and renders only the samples of [0, spp) it lacks (e.g. 100 spp today, 500 tomorrow).
  */
 #include "craytracer.h"
 
@@ -14,7 +18,8 @@ int main(int argc, char* argv[])
 {
     if (argc < 5) {
         fprintf(stderr, "usage: %s <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|perlin|stress:N] [--seed S] "
-                        "[--strict] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp]\n", argv[0]);
+                        "[--strict] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp] [--checkpoint file] "
+                        "[--resume file]\n", argv[0]);
         return 2;
     }
     const f32 aspect = 16.0f / 9.0f;                 /* src/main.c:64-68 */
@@ -27,6 +32,8 @@ int main(int argc, char* argv[])
     const char* scene_name = "0";
     const char* out_name = "output.bmp";             /* src/main.c:113 */
     const char* texture_name = NULL;
+    const char* checkpoint_name = NULL;
+    const char* resume_name = NULL;
     u32 seed = 0xC0FFEEu;
     int strict = 0;
     i32 batch = 0, jobs = 0;
@@ -38,6 +45,8 @@ int main(int argc, char* argv[])
         else if (!strcmp(argv[k], "--jobs") && k + 1 < argc) jobs = atoi(argv[++k]);
         else if (!strcmp(argv[k], "--texture") && k + 1 < argc) texture_name = argv[++k];
         else if (!strcmp(argv[k], "--out") && k + 1 < argc) out_name = argv[++k];
+        else if (!strcmp(argv[k], "--checkpoint") && k + 1 < argc) checkpoint_name = argv[++k];
+        else if (!strcmp(argv[k], "--resume") && k + 1 < argc) resume_name = argv[++k];
         else { fprintf(stderr, "unknown argument: %s\n", argv[k]); return 2; }
     }
     if (height < 2 || width < 2 || spp < 1) { fprintf(stderr, "height >= 2 and spp >= 1 are required\n"); return 2; }
@@ -70,6 +79,11 @@ int main(int argc, char* argv[])
     ray_dispatcher_set_strict(&dispatcher, strict);
     ray_dispatcher_set_batch(&dispatcher, batch);
     if (jobs > 0) ray_dispatcher_set_jobs(&dispatcher, jobs);      /* more jobs than GPUs: they share the devices */
+    if (checkpoint_name) ray_dispatcher_set_checkpoint(&dispatcher, checkpoint_name);
+    if (resume_name && ray_dispatcher_resume(&dispatcher, resume_name) != 0) {
+        free_ray_dispatcher(&dispatcher);
+        return 1;
+    }
 
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);

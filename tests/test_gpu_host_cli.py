@@ -57,3 +57,36 @@ def test_cli_three_jobs_on_one_gpu_sum_to_the_same_frame(tmp_path, ca, orc):
     assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a == b).mean() > 0.999     # float sums regrouped per job
     rays = [int(o[1].split("Rays: ")[1].split()[0]) for o in outs]
     assert rays[0] == rays[1]
+
+
+def test_cli_checkpoint_and_resume_give_the_uninterrupted_frame(tmp_path, ca):
+    """A frame rendered in two runs (5 of 12 samples, checkpoint; the other 7 by two jobs, resumed)
+    holds the same paths as one run of 12 samples; a checkpoint of another seed is refused."""
+    exe = os.path.join(os.path.dirname(ca.lib_paths()["host"]), "craytracer")
+    height, depth, seed = 54, 50, 31
+    common = ["--scene", "rtiow", "--strict", "--seed", str(seed)]
+    whole, part, ck, ck2 = (str(tmp_path / n) for n in ("whole.bmp", "part.bmp", "frame.ck", "frame2.ck"))
+
+    def run(spp, *extra):
+        return subprocess.run([exe, str(height), str(spp), str(depth), "1", *common, *extra], capture_output=True, text=True, timeout=120)
+
+    p0 = run(12, "--out", whole)
+    p1 = run(5, "--out", part, "--checkpoint", ck)
+    p2 = run(12, "--out", part, "--resume", ck, "--jobs", "2", "--checkpoint", ck2)
+    for p in (p0, p1, p2):
+        assert p.returncode == 0, p.stderr
+    rays = [int(p.stdout.split("Rays: ")[1].split()[0]) for p in (p0, p1, p2)]
+    assert rays[1] + rays[2] == rays[0]
+    width = int(np.float32(height) * (np.float32(16.0) / np.float32(9.0)))
+    a = _bmp_pixels(open(whole, "rb").read(), width, height)
+    b = _bmp_pixels(open(part, "rb").read(), width, height)
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a == b).mean() > 0.999      # float sums regrouped per run
+    # the second checkpoint holds the whole range; resuming it renders nothing and writes the same image
+    p3 = run(12, "--out", str(tmp_path / "again.bmp"), "--resume", ck2)
+    assert p3.returncode == 0 and "Rays: 0 " in p3.stdout
+    assert open(tmp_path / "again.bmp", "rb").read() == open(part, "rb").read()
+    sums = np.fromfile(ck2, dtype=np.float32, offset=8 + 5 * 4 + 8 + 8 + 8).reshape(height, width, 4)
+    assert np.all(sums[..., 3] == 12)
+    bad = subprocess.run([exe, str(height), "12", str(depth), "1", "--scene", "rtiow", "--strict", "--seed", "32", "--resume", ck],
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "another frame" in bad.stderr

@@ -155,3 +155,80 @@ def test_sample_partition():
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
     with pytest.raises(ValueError):
         sample_partition(10, 2, 2)
+
+
+def test_sample_range_lists_and_checkpoint_file(tmp_path, ca):
+    """The bookkeeping of progressive rendering: which samples a frame holds, which are left, how the
+    rest is dealt out to the jobs, and the checkpoint file's round trip and refusals."""
+    import craytracer_amd.binding as b
+
+    host = b.load_host_lib()
+    R = np.dtype([("begin", "<i4"), ("count", "<i4")])
+
+    def arr(pairs, cap=None):
+        a = np.zeros(cap or max(len(pairs), 1), R)
+        for k, (s, c) in enumerate(pairs):
+            a[k] = (s, c)
+        return a
+
+    def ptr(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def as_set(a, n):
+        s = set()
+        for k in range(n):
+            s.update(range(int(a["begin"][k]), int(a["begin"][k] + a["count"][k])))
+        return s
+
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        pairs = [(int(rng.integers(0, 60)), int(rng.integers(0, 9))) for _ in range(int(rng.integers(0, 7)))]
+        a = arr(pairs)
+        want = as_set(a, len(pairs))
+        n = host.crt_ranges_normalize(ptr(a), len(pairs))
+        assert as_set(a, n) == want and host.crt_ranges_total(ptr(a), n) == len(want)
+        assert all(a["begin"][k] + a["count"][k] < a["begin"][k + 1] for k in range(n - 1))       # sorted, merged
+        spp = int(rng.integers(0, 80))
+        rest = arr([], 16)
+        m = host.crt_ranges_complement(ptr(a), n, spp, ptr(rest), 16)
+        assert as_set(rest, m) == set(range(spp)) - want
+        # dealing the rest out to G jobs: disjoint slices, in order, sizes within one of each other
+        total = host.crt_ranges_total(ptr(rest), m)
+        G = int(rng.integers(1, 5))
+        got = []
+        for g in range(G):
+            first, last = total * g // G, total * (g + 1) // G
+            part = arr([], 16)
+            k = host.crt_ranges_slice(ptr(rest), m, first, last - first, ptr(part), 16)
+            s = as_set(part, k)
+            assert len(s) == last - first == host.crt_ranges_total(ptr(part), k)
+            got.append(s)
+        assert set().union(*got) == set(range(spp)) - want and sum(len(s) for s in got) == total
+    assert host.crt_ranges_complement(ptr(arr([(2, 1), (5, 1), (8, 1)])), 3, 20, ptr(arr([], 2)), 2) == -1      # cap too small
+
+    # the file: header fields, ranges and sums survive; truncated, padded and foreign files are refused
+    class CP(ctypes.Structure):
+        _fields_ = [("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("seed", ctypes.c_uint32),
+                    ("strict", ctypes.c_int32), ("max_depth", ctypes.c_int32), ("scene_hash", ctypes.c_uint64),
+                    ("n_ranges", ctypes.c_int32), ("ranges", ctypes.c_int32 * 512), ("sums", ctypes.c_void_p)]
+
+    host.crt_checkpoint_read.restype = ctypes.POINTER(CP)
+    sums = rng.random((3, 5, 4), dtype=np.float32)
+    cp = CP(5, 3, 77, 1, 50, 0x1234567890ABCDEF, 2)
+    cp.ranges[0:4] = [10, 4, 0, 6]
+    cp.sums = sums.ctypes.data
+    path = str(tmp_path / "a.ck").encode()
+    assert host.crt_checkpoint_write(path, ctypes.byref(cp)) == 0
+    back = host.crt_checkpoint_read(path)
+    assert back and (back.contents.width, back.contents.height, back.contents.seed, back.contents.strict,
+                     back.contents.max_depth, back.contents.scene_hash) == (5, 3, 77, 1, 50, 0x1234567890ABCDEF)
+    assert back.contents.n_ranges == 2 and list(back.contents.ranges[0:4]) == [0, 6, 10, 4]     # normalized on reading
+    got = np.ctypeslib.as_array(ctypes.cast(back.contents.sums, ctypes.POINTER(ctypes.c_float)), shape=(3, 5, 4))
+    assert np.array_equal(got, sums)
+    host.crt_checkpoint_free(back)
+    data = open(path, "rb").read()
+    for name, blob in (("short", data[:-4]), ("long", data + b"\0"), ("magic", b"X" + data[1:]), ("empty", b"")):
+        p = str(tmp_path / name).encode()
+        open(p, "wb").write(blob)
+        assert not host.crt_checkpoint_read(p)
+    assert not host.crt_checkpoint_read(str(tmp_path / "missing").encode())
