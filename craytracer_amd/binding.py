@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_DIR = os.path.join(_HERE, "lib")
 
 STRICT = 1
+VECTOR_LOOP = 2      # evaluate the sphere filter on the vector unit (A/B against the matrix cores)
 
 OBJECT_DTYPE = np.dtype([("type", "<i4"), ("material", "<i4"), ("g", "<f4", (6,))])
 MATERIAL_DTYPE = np.dtype(
@@ -350,12 +351,12 @@ class CasterHip:
         )
 
     # -- the hot path
-    def render(self, cam, width, height, sample_begin, sample_count, max_depth, seed, accum_ptr: int, strict=False):
+    def render(self, cam, width, height, sample_begin, sample_count, max_depth, seed, accum_ptr: int, strict=False, vector_loop=False):
         cam = _f32(cam, (19,))
         _check(
             self._lib.caster_hip_render(
                 self._ctx, _ptr(cam), C.c_int(width), C.c_int(height), C.c_int(sample_begin), C.c_int(sample_count),
-                C.c_int(max_depth), C.c_uint32(seed), C.c_uint32(STRICT if strict else 0), C.c_void_p(accum_ptr),
+                C.c_int(max_depth), C.c_uint32(seed), C.c_uint32((STRICT if strict else 0) | (VECTOR_LOOP if vector_loop else 0)), C.c_void_p(accum_ptr),
             ),
             "caster_hip_render",
         )
@@ -379,13 +380,13 @@ class CasterHip:
             "caster_hip_resolve_dev",
         )
 
-    def render_image(self, cam, width, height, spp, max_depth, seed, strict=False, sample_begin=0):
+    def render_image(self, cam, width, height, spp, max_depth, seed, strict=False, sample_begin=0, vector_loop=False):
         """Convenience: allocate, render, return (sums [h, w, 4] float32 with j = 0 at the bottom, rays, kernel ms)."""
         nbytes = width * height * 16
         acc = self.malloc(nbytes)
         try:
             self.memset_zero(acc, nbytes)
-            self.render(cam, width, height, sample_begin, spp, max_depth, seed, acc, strict=strict)
+            self.render(cam, width, height, sample_begin, spp, max_depth, seed, acc, strict=strict, vector_loop=vector_loop)
             rays, ms = self.render_stats()
             sums = self.download(acc, (height, width, 4), np.float32)
         finally:
@@ -429,13 +430,13 @@ class CasterHip:
         )
         return dict(hit=hit, t=t, p=p3, n=n3, face=face, mat=mat)
 
-    def test_trace(self, ray6, strict=True):
+    def test_trace(self, ray6, strict=True, vector_loop=False):
         ray6 = _f32(ray6, (-1, 6))
         n = len(ray6)
         hit, face, mat = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
         t, p3, n3 = np.zeros(n, np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
         _check(
-            self._lib.caster_hip_test_trace(self._ctx, C.c_uint32(STRICT if strict else 0), C.c_int(n), _ptr(ray6), _ptr(hit),
+            self._lib.caster_hip_test_trace(self._ctx, C.c_uint32((STRICT if strict else 0) | (VECTOR_LOOP if vector_loop else 0)), C.c_int(n), _ptr(ray6), _ptr(hit),
                                             _ptr(t), _ptr(p3), _ptr(n3), _ptr(face), _ptr(mat)),
             "caster_hip_test_trace",
         )

@@ -202,6 +202,86 @@ int caster_hip_set_chunk(caster_hip_ctx* ctx, int samples_per_unit)
     return CASTER_HIP_OK;
 }
 
+// Operand tables of the matrix-core filter (layout and arithmetic: caster_render.hpp).  A scene
+// qualifies when every sphere that is not tested directly has finite filter entries and the list
+// entries can name its blocks; otherwise mfma_blocks stays 0 and the vector loop runs.
+static void split_half_host(double x, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)(float)x;
+    lo = (_Float16)(float)(x - (double)(float)hi);
+}
+
+static int build_matrix_tables(caster_hip_ctx* ctx, const std::vector<float4>& sph, const std::vector<float4>& sph_filter,
+                               const std::vector<float>& sph_scale)
+{
+    caster::SceneDev& s = ctx->scene;
+    s.mfma_tab[0] = s.mfma_tab[1] = nullptr;
+    s.mfma_blocks = 0;
+    s.mfma_scale = 1.0f;
+    const size_t n = sph.size();
+    const size_t n_blocks = (n + 31) / 32;
+    if (n == 0 || n_blocks > (size_t)caster::kMfmaMaxBlocks) return CASTER_HIP_OK;
+    double extent = 0.0;
+    for (size_t k = 0; k < n; ++k) {
+        const float4 f = sph_filter[k];            // c'x, c'y, c'z, C - r*r (+inf: tested directly, -inf: huge but not listed)
+        if (f.w == INFINITY) continue;
+        if (f.w == -INFINITY || !std::isfinite(f.x) || !std::isfinite(f.y) || !std::isfinite(f.z)) return CASTER_HIP_OK;
+        extent = std::max(extent, std::max(std::max(fabs((double)f.x), fabs((double)f.y)), fabs((double)f.z)));
+        extent = std::max(extent, fabs((double)sph[k].w));
+    }
+    // scaled extents in (32, 64]: squares and K stay below 2^14, far inside half-precision range
+    int e = 0;
+    if (extent > 0.0 && std::isfinite(extent)) {
+        (void)frexp(extent, &e);                   // extent = m * 2^e, m in [0.5, 1)
+        e = 6 - e;
+        if (e > 100) e = 100;
+        if (e < -100) e = -100;
+    }
+    const double scale = ldexp(1.0, e);
+    s.mfma_scale = (float)scale;
+    for (int mode = 0; mode < 2; ++mode) {
+        const double g = (double)(mode ? caster::kFilterMarginStrict : caster::kFilterMarginFast) +
+                         (double)caster::kFilterMarginMfmaExtra;
+        std::vector<_Float16> tab((n_blocks + 1) * 2 * 64 * 8, (_Float16)0.0f);
+        for (size_t k = 0; k < (n_blocks + 1) * 32; ++k) {
+            _Float16 slot[32];
+            for (int i = 0; i < 32; ++i) slot[i] = (_Float16)0.0f;
+            const bool live = k < n && sph_filter[k].w != INFINITY;
+            if (live) {
+                const double cx = (double)sph_filter[k].x * scale, cy = (double)sph_filter[k].y * scale,
+                             cz = (double)sph_filter[k].z * scale;
+                const double r = (double)sph[k].w * scale;
+                const double C = cx * cx + cy * cy + cz * cz, r2 = r * r;
+                const double feat[9] = {cx * cx, cy * cy, cz * cz, cx * cy, cx * cz, cy * cz, cx, cy, cz};
+                for (int f = 0; f < 9; ++f) {
+                    _Float16 hi, lo;
+                    split_half_host(feat[f], hi, lo);
+                    slot[3 * f] = hi; slot[3 * f + 1] = hi; slot[3 * f + 2] = lo;
+                }
+                // the constant of the key, with the sphere's share of the margin and an absolute
+                // term for what half-precision subnormals lose
+                const double Z = g * (C + r2) - (C - r2) + 4.0e-6;
+                split_half_host(Z, slot[27], slot[28]);
+            } else {
+                slot[27] = (_Float16)(-60000.0f);   // never a candidate: pad rows and the spheres that are tested directly
+            }
+            (void)sph_scale;
+            const size_t blk = k / 32, r = k % 32;
+            for (int q = 0; q < 2; ++q)
+                for (int h = 0; h < 2; ++h)
+                    for (int j = 0; j < 8; ++j)
+                        tab[(((blk * 2 + q) * 64) + (size_t)h * 32 + r) * 8 + j] = slot[16 * q + 8 * h + j];
+        }
+        static_assert(sizeof(_Float16) == 2, "half size");
+        std::vector<uint4> img(tab.size() / 8);
+        memcpy(img.data(), tab.data(), img.size() * sizeof(uint4));
+        int rc;
+        if ((rc = upload_array(ctx, img, &s.mfma_tab[mode]))) return rc;
+    }
+    s.mfma_blocks = (int)n_blocks;
+    return CASTER_HIP_OK;
+}
+
 int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_object* objects,
                             int n_materials, const caster_material* materials,
                             int n_images, const caster_image* images)
@@ -311,6 +391,7 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
         if ((rc = upload_array(ctx, img, &s.filter_img[mode]))) return rc;
     }
     s.ref[0] = (float)ref[0]; s.ref[1] = (float)ref[1]; s.ref[2] = (float)ref[2];
+    if ((rc = build_matrix_tables(ctx, sph, sph_filter, sph_scale))) return rc;
     if ((rc = upload_array(ctx, sph_meta, &s.sph_meta))) return rc;
     if ((rc = upload_array(ctx, rect_a, &s.rect_a))) return rc;
     if ((rc = upload_array(ctx, rect_b, &s.rect_b))) return rc;
@@ -449,7 +530,8 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
         return fail(CASTER_HIP_ERR_ARG, "frame size %dx%d out of range", width, height);
     if (sample_begin < 0 || sample_count < 0) return fail(CASTER_HIP_ERR_ARG, "negative sample range");
-    if ((flags & ~(uint32_t)CASTER_HIP_STRICT) != 0) return fail(CASTER_HIP_ERR_ARG, "unknown flag bits 0x%x", flags);
+    if ((flags & ~(uint32_t)(CASTER_HIP_STRICT | CASTER_HIP_VECTOR_LOOP)) != 0)
+        return fail(CASTER_HIP_ERR_ARG, "unknown flag bits 0x%x", flags);
     DeviceGuard guard(ctx->device);
     HIP_TRY(hipMemsetAsync(ctx->rays_dev, 0, 2 * sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
@@ -474,6 +556,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     caster::RenderArgs a;
     a.cam = cam_rec(cam);
     a.scene = ctx->scene;
+    if (flags & CASTER_HIP_VECTOR_LOOP) a.scene.mfma_blocks = 0;
     a.width = width; a.height = height;
     a.s_begin = sample_begin; a.s_count = sample_count;
     a.n_chunks = plan_chunks(ctx, width, height, sample_count, a.chunk_start);
@@ -667,7 +750,9 @@ int caster_hip_test_trace(caster_hip_ctx* ctx, uint32_t flags, int n, const floa
     HIP_TRY(dn.alloc(sizeof(float) * 3 * n));
     HIP_TRY(df.alloc(sizeof(int32_t) * n));
     HIP_TRY(dm.alloc(sizeof(int32_t) * n));
-    HIP_TRY(PICK(flags, launch_test_trace_)(ctx->scene, n, dr.as<float>(), dhit.as<int32_t>(), dtt.as<float>(),
+    caster::SceneDev scene = ctx->scene;
+    if (flags & CASTER_HIP_VECTOR_LOOP) scene.mfma_blocks = 0;
+    HIP_TRY(PICK(flags, launch_test_trace_)(scene, n, dr.as<float>(), dhit.as<int32_t>(), dtt.as<float>(),
                                             dp.as<float>(), dn.as<float>(), df.as<int32_t>(), dm.as<int32_t>(),
                                             ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

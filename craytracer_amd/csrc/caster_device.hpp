@@ -115,6 +115,7 @@ struct SceneView {
     const float4* sph_filter;
     const float*  sph_scale;
     const float4* filter_img;
+    const uint4* mfma_tab;
     const float4* rect_a;   // cx, cy, cz, du
     const float4* rect_b;   // dv, -, -, -
     const int2*   rect_meta;

@@ -26,6 +26,7 @@ CDEV SceneView view_of(const SceneDev& s)
     v.n_sph = s.n_sph; v.n_rect = s.n_rect; v.n_mat = s.n_mat; v.n_img = s.n_img;
     v.has_noise = false; v.noise_vec = nullptr; v.noise_perm = nullptr;      // see stage_noise
     v.filter_img = s.filter_img[CASTER_STRICT];
+    v.mfma_tab = s.mfma_tab[CASTER_STRICT];
     return v;
 }
 

@@ -23,6 +23,10 @@ struct CamRec { float o[3], llc[3], h[3], v[3], u0[3], v0[3]; float lr; };
 constexpr int kMaxAlways = 4;
 constexpr float kFilterMarginStrict = 1.0e-5f;   // candidate-filter margins of the two arithmetic modes
 constexpr float kFilterMarginFast = 2.5e-6f;
+// The matrix-core form of the filter (see caster_render.hpp) adds the error of its two-piece
+// half-precision operands and of the matrix unit's accumulation to those margins.
+constexpr float kFilterMarginMfmaExtra = 3.0e-5f;
+constexpr int kMfmaMaxBlocks = 511;    // sphere blocks of 32 that a candidate list entry can name
 
 struct SceneDev {
     const float4* sph;       // cx, cy, cz, r            (list order among spheres)
@@ -39,6 +43,9 @@ struct SceneDev {
     float ref[3];            // P, the reference point of the candidate filter
     const float4* noise_vec; // 256 unit vectors (w unused), or null
     const uint8_t* noise_perm; // perm_x[256], perm_y[256], perm_z[256], or null
+    const uint4* mfma_tab[2];// matrix-core filter operands (fast, strict): [block][2][64 lanes] x 8 halves, or null
+    int mfma_blocks;         // blocks of 32 spheres in mfma_tab; 0: the scene does not qualify
+    float mfma_scale;        // power of two that brings the scene into half-precision range
     int n_always;            // spheres tested directly for every ray, outside the filter
     int always[kMaxAlways];  // their indices
 };

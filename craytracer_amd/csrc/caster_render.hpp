@@ -107,8 +107,6 @@ struct Unit {
 
 constexpr int kAccStride = kTileW * kTileH * 3;     // one accumulator set: 64 pixels x RGB
 typedef unsigned long long acc_t;                   // fixed point, 32 fractional bits
-// LDS in front of the sphere image: accumulators, candidate lists
-constexpr int kLdsFixedBytes = (int)sizeof(unsigned long long) * kWaves * kAccStride + 2 * kWaves * kListCap * 64;
 
 // Pulls the next unit off the queue.  Units are numbered chunk-major.
 CDEV Unit fetch_unit(const RenderArgs& a, int tiles_x, int n_tiles, int lane)
@@ -474,6 +472,259 @@ CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, 
     drain_candidates(cl, lds, base, sa, sb, closestA, closestB, bestA, bestB, tm);
 }
 
+// ---- sphere loop on the matrix cores -------------------------------------
+// The candidate key is bilinear in a feature vector of the sphere and one of the ray:
+//     (c'.u)^2 + (2w).c' + Z  =  sum_f S_f R_f + Z ,
+//     S = (cx^2, cy^2, cz^2, cx cy, cx cz, cy cz, cx, cy, cz)          c' = scale * (c - P)
+//     R = (ux^2, uy^2, uz^2, 2 ux uy, 2 ux uz, 2 uy uz, 2 wx, 2 wy, 2 wz)
+// so the keys of 32 spheres and 32 rays are a 32 x 32 matrix product, and the matrix cores
+// compute it while the vector unit only looks for the largest key.  The operands are
+// half-precision: every feature is split into two halves x = hi + lo (22 bits together) and
+// the three products hi*hi, hi*lo, lo*hi are summed (the matrix unit multiplies exactly and
+// accumulates in FP32): 27 of the 32 k-slots of two v_mfma_f32_32x32x16_f16, two more for
+// Z = Zhi + Zlo against a ray entry of 1.  The power-of-two scale keeps every sphere feature
+// within half-precision range; what is lost against the FP32 form of the filter is covered by
+// a larger margin (kFilterMarginMfmaExtra) and an absolute term in Z.
+//
+// Operand layout (lane l, r = l & 31, h = l >> 5): the sphere operand of block b and k-half q
+// comes ready-made from the table, mfma_tab[(2b + q) * 64 + l] = slots 16q + 8h .. + 7 of
+// sphere 32b + r.  A wave's 128 rays form four column blocks: block 2s + g holds slot s of
+// lanes 32g .. 32g + 31.  Each lane builds the 32 slots of its own two rays; one
+// v_permlane32_swap per register then leaves lane l with slots 16q + 8h .. of ray r of the
+// column block, which is where the instruction wants them.  The result has the ray on the
+// lane and 16 spheres in the registers: rows 8(v >> 2) + 4h + (v & 3), v = 0..15.
+//
+// A lane that finds a candidate is not the lane that owns the ray.  It appends a 16-bit entry
+// (slot, block, register quad, four bits) to a list of the owner's in LDS: every owner has two
+// lists, one per half h of the wave, so each list has exactly one writer and needs no atomics.
+// After the loop (or when a list may run full) the writers end their lists with a mark and
+// every lane works off its own two lists with the reference's arithmetic (candidate_root).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+
+constexpr int kMfmaListCap = 16;                                      // entries per list (one more slot holds the end mark)
+constexpr int kMfmaListWords = (kMfmaListCap + 1) * 2 * 64;           // u16 per wave
+constexpr unsigned int kMfmaEndMark = 0xFFFFu;
+#if CASTER_STRICT
+constexpr float kFilterMarginMfma = kFilterMarginStrict + kFilterMarginMfmaExtra;
+#else
+constexpr float kFilterMarginMfma = kFilterMarginFast + kFilterMarginMfmaExtra;
+#endif
+
+struct RayHalves {
+    h8 f00, f01, f10, f11;      // slots 0-7, 8-15, 16-23, 24-31
+    float thr;
+    bool finite;
+};
+
+CDEV void split_half(float x, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+CDEV RayHalves ray_halves(const Slot& s, const float3 ref, float scale)
+{
+    RayHalves r;
+    const float qx = (s.o.x - ref.x) * scale, qy = (s.o.y - ref.y) * scale, qz = (s.o.z - ref.z) * scale;
+#if CASTER_STRICT
+    const float inv = __frsqrt_rn(s.aa);
+    const float ux = s.d.x * inv, uy = s.d.y * inv, uz = s.d.z * inv;
+#else
+    const float ux = s.d.x, uy = s.d.y, uz = s.d.z;
+#endif
+    const float oo = qx * qx + qy * qy + qz * qz;
+    const float od = qx * ux + qy * uy + qz * uz;
+    const float wx = qx - od * ux, wy = qy - od * uy, wz = qz - od * uz;
+    float thr = (wx * wx + wy * wy + wz * wz) - oo * kFilterMarginMfma;
+    r.finite = (thr - thr == 0.0f);
+    float f[9] = {ux * ux, uy * uy, uz * uz, 2.0f * ux * uy, 2.0f * ux * uz, 2.0f * uy * uz, wx + wx, wy + wy, wz + wz};
+    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f[6]), __builtin_fabsf(f[7])), __builtin_fabsf(f[8]));
+    // A slot without a path, or a non-finite ray (non_finite_rule decides for it): never a
+    // candidate.  A ray so far out that its features leave half-precision range: a candidate for
+    // every sphere (the list code then runs the exact test on all of them).
+    const bool never = !s.alive || !r.finite;
+    const bool all = !never && !(big < 60000.0f);
+    if (never || all) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) f[k] = 0.0f;
+        thr = never ? __builtin_inff() : -__builtin_inff();
+    }
+    r.thr = thr;
+    _Float16 h[9], l[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) split_half(f[k], h[k], l[k]);
+    const _Float16 one = (_Float16)1.0f, zero = (_Float16)0.0f;
+    // slot 3f: hi (against the sphere's hi), 3f+1: lo (against hi), 3f+2: hi (against lo)
+    r.f00 = h8{h[0], l[0], h[0], h[1], l[1], h[1], h[2], l[2]};
+    r.f01 = h8{h[2], h[3], l[3], h[3], h[4], l[4], h[4], h[5]};
+    r.f10 = h8{l[5], h[5], h[6], l[6], h[6], h[7], l[7], h[7]};
+    r.f11 = h8{h[8], l[8], h[8], one, one, zero, zero, zero};
+    return r;
+}
+
+// x keeps its lower 32 lanes and takes those of y into its upper half; y keeps its upper 32
+// lanes and takes those of x into its lower half.
+CDEV void swap_halves(unsigned int& x, unsigned int& y)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+CDEV void swap_halves(h8& x, h8& y)
+{
+    uint4 a = __builtin_bit_cast(uint4, x), b = __builtin_bit_cast(uint4, y);
+    swap_halves(a.x, b.x); swap_halves(a.y, b.y); swap_halves(a.z, b.z); swap_halves(a.w, b.w);
+    x = __builtin_bit_cast(h8, a);
+    y = __builtin_bit_cast(h8, b);
+}
+
+struct MfmaRays {
+    h8 b00, b01, b10, b11, b20, b21, b30, b31;      // b<column block><k-half>
+    float thr0, thr1, thr2, thr3;
+    bool finiteA, finiteB;
+};
+
+CDEV MfmaRays pack_rays_mfma(const Slot& sa, const Slot& sb, const float3 ref, float scale)
+{
+    RayHalves ra = ray_halves(sa, ref, scale);
+    RayHalves rb = ray_halves(sb, ref, scale);
+    MfmaRays m;
+    m.finiteA = ra.finite; m.finiteB = rb.finite;
+    swap_halves(ra.f00, ra.f01); swap_halves(ra.f10, ra.f11);
+    swap_halves(rb.f00, rb.f01); swap_halves(rb.f10, rb.f11);
+    m.b00 = ra.f00; m.b10 = ra.f01; m.b01 = ra.f10; m.b11 = ra.f11;
+    m.b20 = rb.f00; m.b30 = rb.f01; m.b21 = rb.f10; m.b31 = rb.f11;
+    unsigned int t0 = __float_as_uint(ra.thr), t1 = t0, t2 = __float_as_uint(rb.thr), t3 = t2;
+    swap_halves(t0, t1);
+    swap_halves(t2, t3);
+    m.thr0 = __uint_as_float(t0); m.thr1 = __uint_as_float(t1);
+    m.thr2 = __uint_as_float(t2); m.thr3 = __uint_as_float(t3);
+    return m;
+}
+
+struct MfmaLists {
+    unsigned short* mem;    // this wave's: entry p of the list (owner lane w, writer half h) at mem[(2p + h) * 64 + w]
+    int cnt0, cnt1;         // entries this lane has written to the lists of its owners r and 32 + r
+};
+
+CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact, const Slot& sa, const Slot& sb,
+                     float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
+{
+    const unsigned long long t0 = tm.now();
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5, r = lane & 31;
+    ml.mem[(2 * ml.cnt0 + h) * 64 + r] = (unsigned short)kMfmaEndMark;
+    ml.mem[(2 * ml.cnt1 + h) * 64 + 32 + r] = (unsigned short)kMfmaEndMark;
+    ml.cnt0 = ml.cnt1 = 0;
+    // LDS instructions of one wave complete in order: the reads below see the writes above
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int list = 0, pos = 0;
+    unsigned int bits = 0, meta = 0;
+    bool more = true;
+    for (;;) {
+        if (bits == 0 && more) {
+            const unsigned int e = ml.mem[(2 * pos + list) * 64 + lane];
+            if (e == kMfmaEndMark) {
+                if (list == 0) { list = 1; pos = 0; } else more = false;
+            } else {
+                ++pos;
+                bits = e & 15u;
+                meta = (e >> 4) | ((unsigned int)list << 16);
+            }
+        }
+        if (!__any(bits != 0 || more)) break;
+        CASTER_STAT(1);
+        if (bits != 0) {
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1u;
+            // meta: bits 0-1 register quad, 2-10 block, 11 slot, 16 writer half
+            const int k = (int)((meta >> 2) & 511u) * 32 + (int)(meta & 3u) * 8 + (int)(meta >> 16) * 4 + b;
+            const bool second = ((meta >> 11) & 1u) != 0;
+            if (k < sc.n_sph) {
+                V3 o, d;
+                o.x = second ? sb.o.x : sa.o.x; o.y = second ? sb.o.y : sa.o.y; o.z = second ? sb.o.z : sa.o.z;
+                d.x = second ? sb.d.x : sa.d.x; d.y = second ? sb.d.y : sa.d.y; d.z = second ? sb.d.z : sa.d.z;
+                const float aa = second ? sb.aa : sa.aa;
+                const float tmin = second ? sb.tmin : sa.tmin;
+                const float4 e = lds_exact[k];
+                float t;
+                if (candidate_root(e, o, d, aa, tmin, t)) {
+                    float closest = second ? closestB : closestA;
+                    int best = second ? bestB : bestA;
+                    take_hit(t, k, closest, best);
+                    closestA = second ? closestA : closest; bestA = second ? bestA : best;
+                    closestB = second ? closest : closestB; bestB = second ? best : bestB;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    tm.add(WaveTimers::kLists, t0);
+}
+
+// The keys of one column block against one sphere block: two matrix instructions, the largest
+// of the lane's 16 keys, and (rarely) list entries for the keys that reach the threshold.
+template <int CB>
+CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, float thr, int blk, MfmaLists& ml,
+                      const SceneView& sc, const float4* lds_exact, const Slot& sa, const Slot& sb,
+                      float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
+{
+    f16x acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+    float m = __builtin_fmaxf(acc[0], acc[1]);
+#pragma unroll
+    for (int v = 2; v < 16; ++v) m = __builtin_fmaxf(m, acc[v]);
+    const bool mine = m >= thr;
+    if (__any(mine)) {
+        CASTER_STAT(12);
+        int cnt = (CB & 1) ? ml.cnt1 : ml.cnt0;
+        if (__any(cnt > kMfmaListCap - 4)) {
+            drain_mfma(ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+            cnt = 0;
+        }
+        if (mine) {
+            const int lane = threadIdx.x & 63;
+            unsigned short* dst = ml.mem + (lane >> 5) * 64 + (CB & 1) * 32 + (lane & 31);
+#pragma unroll
+            for (int vq = 0; vq < 4; ++vq) {
+                const unsigned int bits = (acc[4 * vq] >= thr ? 1u : 0u) | (acc[4 * vq + 1] >= thr ? 2u : 0u) |
+                                          (acc[4 * vq + 2] >= thr ? 4u : 0u) | (acc[4 * vq + 3] >= thr ? 8u : 0u);
+                if (bits) {
+                    dst[cnt * 128] = (unsigned short)(((unsigned int)(CB >> 1) << 15) | ((unsigned int)blk << 6) |
+                                                      ((unsigned int)vq << 4) | bits);
+                    ++cnt;
+                }
+            }
+        }
+        if (CB & 1) ml.cnt1 = cnt; else ml.cnt0 = cnt;
+    }
+}
+
+// The sphere loop: all blocks of the table against the wave's four column blocks.  The table
+// holds one block more than the scene needs (read ahead).
+CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks, const MfmaRays& mr, MfmaLists& ml,
+                     const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
+                     WaveTimers& tm)
+{
+    const uint4* tab = sc.mfma_tab + (threadIdx.x & 63);
+    uint4 a0 = tab[0], a1 = tab[64];
+#pragma unroll 1
+    for (int blk = 0; blk < n_blocks; ++blk) {
+        const uint4 n0 = tab[(blk + 1) * 128], n1 = tab[(blk + 1) * 128 + 64];
+        const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
+        mfma_column<0>(A0, A1, mr.b00, mr.b01, mr.thr0, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+        mfma_column<1>(A0, A1, mr.b10, mr.b11, mr.thr1, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+        mfma_column<2>(A0, A1, mr.b20, mr.b21, mr.thr2, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+        mfma_column<3>(A0, A1, mr.b30, mr.b31, mr.thr3, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+        a0 = n0; a1 = n1;
+    }
+    drain_mfma(ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+}
+
 // The spheres that are candidates for every ray (SceneDev::n_always of them) do not go through
 // the lists: each lane tests them for its two slots directly.  Their exact images and list
 // positions sit in LDS (stage_always).
@@ -613,17 +864,29 @@ CDEV void swap_slots(Slot& a, Slot& b)
 #ifndef CASTER_BLOCKS_PER_CU
 #define CASTER_BLOCKS_PER_CU 4
 #endif
-template <bool TILED>
+// The sphere loop of a launch: the packed vector filter with the exact sphere image in LDS, the
+// same streaming the image through LDS in tiles (more than kSphTile spheres), or the matrix-core
+// filter with the exact image in LDS (scenes of up to kSphTile spheres that qualify).
+enum LoopKind { kLoopVector = 0, kLoopVectorTiled = 1, kLoopMatrix = 2 };
+constexpr int lds_fixed_bytes(int kind)
+{
+    return (int)sizeof(unsigned long long) * kWaves * kAccStride +
+           2 * kWaves * (kind >= kLoopMatrix ? kMfmaListWords : kListCap * 64);
+}
+
+template <int KIND>
 __global__ __launch_bounds__(kBlock, CASTER_BLOCKS_PER_CU)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
+    constexpr bool TILED = KIND == kLoopVectorTiled;
+    constexpr bool MATRIX = KIND == kLoopMatrix;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ AlwaysLds s_always;
-    // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists [kWaves][kListCap][64] (u16),
-    // the exact sphere image of one tile, the noise tables
+    // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists (u16; [kWaves][kListCap][64], or
+    // [kWaves][kMfmaListWords] for the matrix loop), the exact sphere image of one tile, the noise tables
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
     unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * kAccStride);
-    float4* s_exact = reinterpret_cast<float4*>(s_dyn + kLdsFixedBytes);
+    float4* s_exact = reinterpret_cast<float4*>(s_dyn + lds_fixed_bytes(KIND));
     float4* s_noise_vec = s_exact + a.lds_spheres;                              // only if the scene has noise tables
 
     SceneView sc = view_of(a.scene);
@@ -639,7 +902,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     for (int k = lane; k < kAccStride; k += 64) wave_acc[k] = 0;
     stage_always(&s_always, a.scene);
     int n_lds = 0;
-    if (!TILED) n_lds = stage_spheres(s_exact, sc, 0, sc.n_sph);
+    if (KIND == kLoopVector || KIND == kLoopMatrix) n_lds = stage_spheres(s_exact, sc, 0, sc.n_sph);
     SphereLds lds;
     lds.exact = s_exact;
     lds.filter = sc.filter_img;
@@ -661,6 +924,9 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     CandLists cl;
     cl.mem = s_cand + wave * kListCap * 64 + lane;
     cl.cnt = 0;
+    MfmaLists ml;
+    ml.mem = s_cand + wave * kMfmaListWords;
+    ml.cnt0 = ml.cnt1 = 0;
     WaveTimers tm;
     tm.start();
     const unsigned long long t_begin = tm.now();
@@ -734,10 +1000,18 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         CASTER_STAT(0);
         tm.trip();
         const unsigned long long t_isect = tm.now();
-        const PairRays pr = pack_rays(sa, sb, ref);
         closestA = sa.tmax; closestB = sb.tmax;     // a root equal to tmax is still accepted
         bestA = bestB = -1;
         test_always(&s_always, a.scene.n_always, sa, sb, closestA, closestB, bestA, bestB);
+        if (MATRIX) {
+            const MfmaRays mr = pack_rays_mfma(sa, sb, ref, a.scene.mfma_scale);
+            isect_mfma(sc, s_exact, a.scene.mfma_blocks, mr, ml, sa, sb, closestA, closestB, bestA, bestB, tm);
+            non_finite_rule(mr.finiteA, sc.n_sph, closestA, bestA);
+            non_finite_rule(mr.finiteB, sc.n_sph, closestB, bestB);
+            tm.add(WaveTimers::kIntersect, t_isect);
+            continue;
+        }
+        const PairRays pr = pack_rays(sa, sb, ref);
         if (!TILED) {
             isect_tile(lds, n_lds, 0, pr, cl, sa, sb, closestA, closestB, bestA, bestB, tm);
         } else {
@@ -777,15 +1051,20 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     const long long units = (long long)tiles_x * tiles_y * a.n_chunks;
     if (units <= 0 || units > 0x7fffffffLL) return hipErrorInvalidValue;
     a.n_units = (int)units;
+    const bool large = a.scene.n_sph > kSphTile;
+    const bool matrix = !large && a.scene.mfma_blocks > 0 && a.scene.mfma_tab[CASTER_STRICT] != nullptr;
+    const int kind = matrix ? kLoopMatrix : (large ? kLoopVectorTiled : kLoopVector);
     a.lds_spheres = lds_sphere_slots(a.scene.n_sph);
-    const size_t lds_bytes = kLdsFixedBytes + sizeof(float4) * (size_t)a.lds_spheres +
+    const size_t lds_bytes = lds_fixed_bytes(kind) + sizeof(float4) * (size_t)a.lds_spheres +
                              (a.scene.noise_vec ? kNoiseLdsBytes : 0);
     long long blocks = (units + kWaves - 1) / kWaves;
     if (blocks > resident_blocks) blocks = resident_blocks;      // persistent: the waves loop over the queue
-    if (a.scene.n_sph > kSphTile)
-        hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<true>, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, st, a);
-    else
-        hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<false>, dim3((unsigned)blocks), dim3(kBlock), lds_bytes, st, a);
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    switch (kind) {
+    case kLoopMatrix: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopMatrix>, grid, block, lds_bytes, st, a); break;
+    case kLoopVectorTiled: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopVectorTiled>, grid, block, lds_bytes, st, a); break;
+    default: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopVector>, grid, block, lds_bytes, st, a); break;
+    }
     return hipGetLastError();
 }
 
@@ -797,7 +1076,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
                                 float* n3, int32_t* face, int32_t* mat)
 {
     __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
-    __shared__ unsigned short s_cand[kWaves * kListCap * 64];
+    __shared__ unsigned short s_cand[kWaves * kMfmaListWords];      // the larger of the two loops' lists
     __shared__ AlwaysLds s_always;
     stage_always(&s_always, sd);
     __syncthreads();
@@ -834,7 +1113,17 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
     cl.cnt = 0;
     WaveTimers tm;
     test_always(&s_always, sd.n_always, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
-    for (int base = 0; base < sc.n_sph; base += kSphTile) {
+    const bool matrix = sd.mfma_blocks > 0 && sc.mfma_tab != nullptr && sc.n_sph <= kSphTile;
+    if (matrix) {
+        stage_spheres(s_exact, sc, 0, sc.n_sph);
+        __syncthreads();
+        MfmaLists ml;
+        ml.mem = s_cand + (threadIdx.x >> 6) * kMfmaListWords;
+        ml.cnt0 = ml.cnt1 = 0;
+        const MfmaRays mr = pack_rays_mfma(sl[0], sl[1], ref, sd.mfma_scale);
+        isect_mfma(sc, s_exact, sd.mfma_blocks, mr, ml, sl[0], sl[1], closest[0], closest[1], best[0], best[1], tm);
+    }
+    for (int base = 0; base < (matrix ? 0 : sc.n_sph); base += kSphTile) {
         const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
         __syncthreads();
         const int padded = stage_spheres(s_exact, sc, base, cnt);
@@ -864,20 +1153,6 @@ hipError_t CASTER_NAME(launch_test_trace_)(const SceneDev& sc, int n, const floa
     const int per_block = kBlock * 2;
     hipLaunchKernelGGL(CASTER_NAME(k_test_trace_), dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), 0,
                        st, sc, n, ray6, hit, t, p3, n3, face, mat);
-    return hipGetLastError();
-}
-
-hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a, hipStream_t st)
-{
-    const int tiles_x = (a.width + kTileW - 1) / kTileW;
-    const int tiles_y = (a.height + kTileH - 1) / kTileH;
-    const long long units = (long long)tiles_x * tiles_y * a.n_chunks;
-    const long long blocks = (units + kWaves - 1) / kWaves;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (a.scene.n_sph > kSphTile)
-        hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<true>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
-    else
-        hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<false>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }
 

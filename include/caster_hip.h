@@ -38,7 +38,11 @@ enum {
     /* Arithmetic in the reference's operation order, no FMA contraction,
      * correctly rounded divide/sqrt.  Without it the kernel may use FMA,
      * reciprocals and a normalised ray direction (same image statistically). */
-    CASTER_HIP_STRICT = 1u
+    CASTER_HIP_STRICT = 1u,
+    /* Evaluate the conservative sphere filter on the vector unit even where the scene qualifies
+     * for the matrix cores.  Both forms hand the same candidates' exact tests to the same code, so
+     * the results are identical; the flag exists for scenes' A/B timing and for the tests. */
+    CASTER_HIP_VECTOR_LOOP = 2u
 };
 
 /* Object, material and texture tags: inc/caster.h:71-75, inc/material.h:17-20,32-35. */

@@ -313,6 +313,12 @@ def test_production_sphere_loop_parity(gpu, orc, ca, scene_name):
         rays[:, 2] -= 1500.0
     rays[-1] = [np.nan, 0, 0, 0, 1, 0]                     # non-finite ray: NaN passes every range test (src/caster.c:107,114)
     g = gpu.test_trace(rays, strict=True)
+    # the filter on the vector unit and on the matrix cores hands the same candidates to the same exact test
+    gv = gpu.test_trace(rays, strict=True, vector_loop=True)
+    for key in ("hit", "mat", "face"):
+        assert np.array_equal(g[key], gv[key])
+    for key in ("t", "p", "n"):
+        assert np.array_equal(g[key], gv[key], equal_nan=True)
     o = orc.hit_list(sc, rays)
     assert np.array_equal(g["hit"], o["hit"])
     h = o["hit"] == 1
@@ -325,6 +331,8 @@ def test_production_sphere_loop_parity(gpu, orc, ca, scene_name):
     assert np.array_equal(g["face"][fin], o["face"][fin])
     # fast mode: same decision except within rounding of a silhouette or of t = tmin
     f = gpu.test_trace(rays[:-1], strict=False)
+    fv = gpu.test_trace(rays[:-1], strict=False, vector_loop=True)
+    assert np.array_equal(f["hit"], fv["hit"]) and np.array_equal(f["mat"], fv["mat"]) and np.array_equal(f["t"], fv["t"], equal_nan=True)
     agree = f["hit"] == o["hit"][:-1]
     assert agree.mean() > 0.985
     both = agree & (o["hit"][:-1] == 1) & (f["mat"] == o["mat"][:-1])

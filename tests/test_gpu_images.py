@@ -44,6 +44,9 @@ def test_strict_image_matches_oracle(gpu, orc, ca, name):
     o, o_rays = orc.render(orc.Scene.from_flat(fs), cam, cfg["w"], cfg["h"], cfg["spp"], cfg["depth"], cfg["seed"])
     assert g_rays == o_rays
     _assert_image_close(g, o, cfg["spp"])
+    # the sphere filter on the vector unit instead of the matrix cores: the same bits
+    v, v_rays, _ = gpu.render_image(cam, cfg["w"], cfg["h"], cfg["spp"], cfg["depth"], cfg["seed"], strict=True, vector_loop=True)
+    assert v_rays == g_rays and np.array_equal(v, g)
     # pixel store: identical bytes after the resolve
     acc = gpu.malloc(g.nbytes)
     try:
@@ -94,6 +97,42 @@ def test_fast_mode_is_scheduling_independent(gpu, ca):
         assert rays == ref_rays
         assert np.array_equal(s, ref)
     gpu.set_chunk(0)
+
+
+@pytest.mark.parametrize("name", ["rtiow", "perlin", "scene_0_textured", "stress_500", "offset"])
+def test_matrix_and_vector_loops_give_identical_frames(gpu, ca, name):
+    """The conservative sphere filter runs on the matrix cores (half-precision pieces, a wider
+    margin) where the scene qualifies and on the vector unit otherwise; either way the candidates go
+    through the same exact test, so whole frames must agree bit for bit in both arithmetic modes,
+    run after run (hundreds of thousands of paths; shading code and textures included, since the two
+    loops are separate kernels)."""
+    if name == "rtiow":
+        fs = ca.scene_rtiow(1)
+    elif name == "perlin":
+        fs = ca.scene_perlin(1)
+    elif name == "scene_0_textured":
+        fs = ca.scene_0(textured=True)
+    elif name == "stress_500":
+        fs = ca.scene_stress(500, 2)
+    else:
+        fs = ca.scene_rtiow(5)                          # far from the origin: the filter's reference point and scale at work
+        objs = fs.objects.copy()
+        objs["g"][:, 0] += 3000.0
+        objs["g"][:, 2] -= 1500.0
+        fs = ca.FlatScene(objs, fs.materials, [])
+    gpu.upload_scene(fs)
+    w, h, spp, depth, seed = 480, 270, 12, 50, 17
+    cam = ca.default_camera(w / h)
+    if name == "offset":
+        cam = ca.calculate_cam_info((3013, 2, -1497), (3000, 0, -1500), (0, 1, 0), 20.0, np.float32(w / h), 0.1, 10.0)
+    for strict in (True, False):
+        m, m_rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=strict)
+        v, v_rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=strict, vector_loop=True)
+        m2, m2_rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=strict)
+        assert m_rays == v_rays == m2_rays
+        assert m_rays > w * h * spp                      # paths do bounce
+        assert np.array_equal(m, v)
+        assert np.array_equal(m, m2)
 
 
 def test_chunk_plan_and_tiled_scene_are_scheduling_independent(gpu, ca):
