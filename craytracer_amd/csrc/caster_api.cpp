@@ -260,11 +260,12 @@ static int build_matrix_tables(caster_hip_ctx* ctx, const std::vector<float4>& s
                 }
                 // the constant of the key, with the sphere's share of the margin and an absolute
                 // term for what half-precision subnormals lose
-                const double Z = g * (C + r2) - (C - r2) + 4.0e-6;
+                const double Z = g * (C + r2) - (C - r2) + 1.0e-4;
                 split_half_host(Z, slot[27], slot[28]);
             } else {
                 slot[27] = (_Float16)(-60000.0f);   // never a candidate: pad rows and the spheres that are tested directly
             }
+            slot[29] = slot[30] = slot[31] = (_Float16)1024.0f;   // against the three halves of -threshold / 1024
             (void)sph_scale;
             const size_t blk = k / 32, r = k % 32;
             for (int q = 0; q < 2; ++q)

@@ -513,9 +513,9 @@ constexpr float kFilterMarginMfma = kFilterMarginFast + kFilterMarginMfmaExtra;
 
 struct RayHalves {
     h8 f00, f01, f10, f11;      // slots 0-7, 8-15, 16-23, 24-31
-    float thr;
     bool finite;
 };
+constexpr float kThrScale = 1024.0f;    // the threshold enters the product as (threshold / kThrScale) * kThrScale: keeps it in half-precision range
 
 CDEV void split_half(float x, _Float16& hi, _Float16& lo)
 {
@@ -536,7 +536,7 @@ CDEV RayHalves ray_halves(const Slot& s, const float3 ref, float scale)
     const float oo = qx * qx + qy * qy + qz * qz;
     const float od = qx * ux + qy * uy + qz * uz;
     const float wx = qx - od * ux, wy = qy - od * uy, wz = qz - od * uz;
-    float thr = (wx * wx + wy * wy + wz * wz) - oo * kFilterMarginMfma;
+    const float thr = (wx * wx + wy * wy + wz * wz) - oo * kFilterMarginMfma;
     r.finite = (thr - thr == 0.0f);
     float f[9] = {ux * ux, uy * uy, uz * uz, 2.0f * ux * uy, 2.0f * ux * uz, 2.0f * uy * uz, wx + wx, wy + wy, wz + wz};
     const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f[6]), __builtin_fabsf(f[7])), __builtin_fabsf(f[8]));
@@ -544,22 +544,26 @@ CDEV RayHalves ray_halves(const Slot& s, const float3 ref, float scale)
     // candidate.  A ray so far out that its features leave half-precision range: a candidate for
     // every sphere (the list code then runs the exact test on all of them).
     const bool never = !s.alive || !r.finite;
-    const bool all = !never && !(big < 60000.0f);
+    const float tneg = -thr * (1.0f / kThrScale);           // three halves of it go against kThrScale in the sphere operand
+    const bool all = !never && !(big < 60000.0f && __builtin_fabsf(tneg) < 60000.0f);
+    _Float16 h[9], l[9];
+    _Float16 t0 = (_Float16)tneg;
+    _Float16 t1 = (_Float16)(tneg - (float)t0);
+    _Float16 t2 = (_Float16)((tneg - (float)t0) - (float)t1);
     if (never || all) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) f[k] = 0.0f;
-        thr = never ? __builtin_inff() : -__builtin_inff();
+        // the key is then the sphere's constant alone (at most 65504 in size) plus 3 * 60000 * kThrScale of either sign
+        t0 = t1 = t2 = (_Float16)(never ? -60000.0f : 60000.0f);
     }
-    r.thr = thr;
-    _Float16 h[9], l[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) split_half(f[k], h[k], l[k]);
-    const _Float16 one = (_Float16)1.0f, zero = (_Float16)0.0f;
+    const _Float16 one = (_Float16)1.0f;
     // slot 3f: hi (against the sphere's hi), 3f+1: lo (against hi), 3f+2: hi (against lo)
     r.f00 = h8{h[0], l[0], h[0], h[1], l[1], h[1], h[2], l[2]};
     r.f01 = h8{h[2], h[3], l[3], h[3], h[4], l[4], h[4], h[5]};
     r.f10 = h8{l[5], h[5], h[6], l[6], h[6], h[7], l[7], h[7]};
-    r.f11 = h8{h[8], l[8], h[8], one, one, zero, zero, zero};
+    r.f11 = h8{h[8], l[8], h[8], one, one, t0, t1, t2};
     return r;
 }
 
@@ -581,7 +585,6 @@ CDEV void swap_halves(h8& x, h8& y)
 
 struct MfmaRays {
     h8 b00, b01, b10, b11, b20, b21, b30, b31;      // b<column block><k-half>
-    float thr0, thr1, thr2, thr3;
     bool finiteA, finiteB;
 };
 
@@ -595,11 +598,6 @@ CDEV MfmaRays pack_rays_mfma(const Slot& sa, const Slot& sb, const float3 ref, f
     swap_halves(rb.f00, rb.f01); swap_halves(rb.f10, rb.f11);
     m.b00 = ra.f00; m.b10 = ra.f01; m.b01 = ra.f10; m.b11 = ra.f11;
     m.b20 = rb.f00; m.b30 = rb.f01; m.b21 = rb.f10; m.b31 = rb.f11;
-    unsigned int t0 = __float_as_uint(ra.thr), t1 = t0, t2 = __float_as_uint(rb.thr), t3 = t2;
-    swap_halves(t0, t1);
-    swap_halves(t2, t3);
-    m.thr0 = __uint_as_float(t0); m.thr1 = __uint_as_float(t1);
-    m.thr2 = __uint_as_float(t2); m.thr3 = __uint_as_float(t3);
     return m;
 }
 
@@ -630,8 +628,8 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
                 if (list == 0) { list = 1; pos = 0; } else more = false;
             } else {
                 ++pos;
-                bits = e & 15u;
-                meta = (e >> 4) | ((unsigned int)list << 16);
+                bits = e & 0xFFu;
+                meta = (e >> 8) | ((unsigned int)list << 16);
             }
         }
         if (!__any(bits != 0 || more)) break;
@@ -639,9 +637,11 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
         if (bits != 0) {
             const int b = __builtin_ctz(bits);
             bits &= bits - 1u;
-            // meta: bits 0-1 register quad, 2-10 block, 11 slot, 16 writer half
-            const int k = (int)((meta >> 2) & 511u) * 32 + (int)(meta & 3u) * 8 + (int)(meta >> 16) * 4 + b;
-            const bool second = ((meta >> 11) & 1u) != 0;
+            // meta: bit 0 upper or lower eight registers, bits 1-5 block, bit 7 slot, bit 16 writer half;
+            // bit b of the entry stands for register v = 8 * (meta & 1) + 7 - b, row 8 (v >> 2) + 4 half + (v & 3)
+            const int v = (int)(meta & 1u) * 8 + 7 - b;
+            const int k = (int)((meta >> 1) & 31u) * 32 + (v >> 2) * 8 + (int)(meta >> 16) * 4 + (v & 3);
+            const bool second = ((meta >> 7) & 1u) != 0;
             if (k < sc.n_sph) {
                 V3 o, d;
                 o.x = second ? sb.o.x : sa.o.x; o.y = second ? sb.o.y : sa.o.y; o.z = second ? sb.o.z : sa.o.z;
@@ -665,41 +665,34 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
     tm.add(WaveTimers::kLists, t0);
 }
 
-// The keys of one column block against one sphere block: two matrix instructions, the largest
-// of the lane's 16 keys, and (rarely) list entries for the keys that reach the threshold.
+// One column block against one sphere block: two matrix instructions leave key - threshold of 16
+// spheres in the lane's registers; a clear sign bit is a candidate.  The 16 signs are gathered
+// into a mask (one v_alignbit each) and a lane with candidates appends up to two list entries,
+// one per eight registers: slot << 15 | block << 9 | upper or lower eight << 8 | the eight bits.
 template <int CB>
-CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, float thr, int blk, MfmaLists& ml,
+CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk, MfmaLists& ml,
                       const SceneView& sc, const float4* lds_exact, const Slot& sa, const Slot& sb,
                       float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
 {
     f16x acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
-    float m = __builtin_fmaxf(acc[0], acc[1]);
+    unsigned int neg = 0u;          // register v ends up in bit 15 - v
 #pragma unroll
-    for (int v = 2; v < 16; ++v) m = __builtin_fmaxf(m, acc[v]);
-    const bool mine = m >= thr;
-    if (__any(mine)) {
+    for (int v = 0; v < 16; ++v) neg = push_sign(neg, acc[v]);
+    const unsigned int cand = ~neg & 0xFFFFu;
+    if (__any(cand != 0u)) {
         CASTER_STAT(12);
         int cnt = (CB & 1) ? ml.cnt1 : ml.cnt0;
-        if (__any(cnt > kMfmaListCap - 4)) {
+        if (__any(cnt > kMfmaListCap - 2)) {
             drain_mfma(ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
             cnt = 0;
         }
-        if (mine) {
-            const int lane = threadIdx.x & 63;
-            unsigned short* dst = ml.mem + (lane >> 5) * 64 + (CB & 1) * 32 + (lane & 31);
-#pragma unroll
-            for (int vq = 0; vq < 4; ++vq) {
-                const unsigned int bits = (acc[4 * vq] >= thr ? 1u : 0u) | (acc[4 * vq + 1] >= thr ? 2u : 0u) |
-                                          (acc[4 * vq + 2] >= thr ? 4u : 0u) | (acc[4 * vq + 3] >= thr ? 8u : 0u);
-                if (bits) {
-                    dst[cnt * 128] = (unsigned short)(((unsigned int)(CB >> 1) << 15) | ((unsigned int)blk << 6) |
-                                                      ((unsigned int)vq << 4) | bits);
-                    ++cnt;
-                }
-            }
-        }
+        const int lane = threadIdx.x & 63;
+        unsigned short* dst = ml.mem + (lane >> 5) * 64 + (CB & 1) * 32 + (lane & 31);
+        const unsigned int head = ((unsigned int)(CB >> 1) << 15) | ((unsigned int)blk << 9);
+        if (cand & 0xFF00u) { dst[cnt * 128] = (unsigned short)(head | (cand >> 8)); ++cnt; }
+        if (cand & 0x00FFu) { dst[cnt * 128] = (unsigned short)(head | 0x100u | (cand & 0xFFu)); ++cnt; }
         if (CB & 1) ml.cnt1 = cnt; else ml.cnt0 = cnt;
     }
 }
@@ -716,10 +709,10 @@ CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks,
     for (int blk = 0; blk < n_blocks; ++blk) {
         const uint4 n0 = tab[(blk + 1) * 128], n1 = tab[(blk + 1) * 128 + 64];
         const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
-        mfma_column<0>(A0, A1, mr.b00, mr.b01, mr.thr0, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-        mfma_column<1>(A0, A1, mr.b10, mr.b11, mr.thr1, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-        mfma_column<2>(A0, A1, mr.b20, mr.b21, mr.thr2, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-        mfma_column<3>(A0, A1, mr.b30, mr.b31, mr.thr3, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+        mfma_column<0>(A0, A1, mr.b00, mr.b01, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+        mfma_column<1>(A0, A1, mr.b10, mr.b11, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+        mfma_column<2>(A0, A1, mr.b20, mr.b21, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+        mfma_column<3>(A0, A1, mr.b30, mr.b31, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
         a0 = n0; a1 = n1;
     }
     drain_mfma(ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
@@ -864,6 +857,10 @@ CDEV void swap_slots(Slot& a, Slot& b)
 #ifndef CASTER_BLOCKS_PER_CU
 #define CASTER_BLOCKS_PER_CU 4
 #endif
+// The same for the kernel of the matrix loop.
+#ifndef CASTER_MATRIX_BLOCKS_PER_CU
+#define CASTER_MATRIX_BLOCKS_PER_CU 4
+#endif
 // The sphere loop of a launch: the packed vector filter with the exact sphere image in LDS, the
 // same streaming the image through LDS in tiles (more than kSphTile spheres), or the matrix-core
 // filter with the exact image in LDS (scenes of up to kSphTile spheres that qualify).
@@ -875,9 +872,10 @@ constexpr int lds_fixed_bytes(int kind)
 }
 
 template <int KIND>
-__global__ __launch_bounds__(kBlock, CASTER_BLOCKS_PER_CU)
+__global__ __launch_bounds__(kBlock, KIND == kLoopMatrix ? CASTER_MATRIX_BLOCKS_PER_CU : CASTER_BLOCKS_PER_CU)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
+    constexpr unsigned int kPerCU = KIND == kLoopMatrix ? CASTER_MATRIX_BLOCKS_PER_CU : CASTER_BLOCKS_PER_CU;
     constexpr bool TILED = KIND == kLoopVectorTiled;
     constexpr bool MATRIX = KIND == kLoopMatrix;
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -931,7 +929,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     tm.start();
     const unsigned long long t_begin = tm.now();
 
-    const unsigned int age = blockIdx.x * (unsigned)CASTER_BLOCKS_PER_CU / gridDim.x;       // blocks are placed in launch order, four per CU
+    const unsigned int age = blockIdx.x * kPerCU / gridDim.x;       // blocks are placed in launch order, kPerCU per CU
     // The unit that feeds the slots.  When its pool is empty its sums so far go to the frame buffer
     // and the wave starts on the next unit at once; the paths still in flight then belong to a tile
     // that is no longer the current one and deposit their radiance in the frame buffer themselves.
@@ -1058,6 +1056,8 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     const size_t lds_bytes = lds_fixed_bytes(kind) + sizeof(float4) * (size_t)a.lds_spheres +
                              (a.scene.noise_vec ? kNoiseLdsBytes : 0);
     long long blocks = (units + kWaves - 1) / kWaves;
+    // resident_blocks counts CASTER_BLOCKS_PER_CU per CU
+    if (kind == kLoopMatrix) resident_blocks = resident_blocks / CASTER_BLOCKS_PER_CU * CASTER_MATRIX_BLOCKS_PER_CU;
     if (blocks > resident_blocks) blocks = resident_blocks;      // persistent: the waves loop over the queue
     const dim3 grid((unsigned)blocks), block(kBlock);
     switch (kind) {
