@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X vector FP32, 256 CU x 256 flop/clk x 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense FP16 matrix peak (no sparsity)
 
 
 def flops_per_ray(n_spheres: int, n_rects: int) -> int:
@@ -199,9 +200,13 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(float(achieved) / FP32_VALU_PEAK_TFLOPS, 4),
                 "traffic": recorded_traffic(f"rtiow_final_scene {W}x{H} {SPP}spp depth{args.depth}", args.mode, world),
-                "kernel": f"caster::render_kernel_{args.mode}<false>",
+                "kernel": f"caster::render_kernel_{args.mode}<2>",
                 "flops_per_ray": flops_per_ray(ns, nr),
-                "note": "no dense contraction on this path: the bound is the FP32 vector (VALU) peak, not MFMA or HBM",
+                "note": "achieved = algorithmic flops (18 per ray-sphere test of the reference's brute-force loop) against the FP32 "
+                        "vector peak, the bound of that algorithm as written; the conservative filter's products now run on the "
+                        "matrix cores (see matrix_cores), so the figure is not capped by the vector peak; the kernel itself is "
+                        "limited by vector-instruction issue (sign masks, exact tests, shading)",
+                "matrix_cores": matrix_core_use(rank_rays, ns, float(np.mean(kernel_ms))),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -211,6 +216,17 @@ def main():
     gpu.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def matrix_core_use(rays, n_spheres, kernel_ms):
+    """Matrix-core work of the candidate filter: every ray meets every block of 32 spheres with two
+    v_mfma_f32_32x32x16_f16 per 32 x 32 keys, 64 flops per key."""
+    if n_spheres > 512:
+        return None                      # the vector loop renders larger scenes
+    rows = (n_spheres + 31) // 32 * 32
+    executed = rays * rows * 64.0 / (kernel_ms * 1e-3) * 1e-12
+    return {"executed": round(executed, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f16 operands, f32 accumulate",
+            "frac": round(executed / F16_MFMA_PEAK_TFLOPS, 4)}
 
 
 def recorded_traffic(workload, mode, world):

@@ -1050,7 +1050,7 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     if (units <= 0 || units > 0x7fffffffLL) return hipErrorInvalidValue;
     a.n_units = (int)units;
     const bool large = a.scene.n_sph > kSphTile;
-    const bool matrix = !large && a.scene.mfma_blocks > 0 && a.scene.mfma_tab[CASTER_STRICT] != nullptr;
+    const bool matrix = !large && a.scene.n_sph >= kMfmaMinSpheres && a.scene.mfma_blocks > 0 && a.scene.mfma_tab[CASTER_STRICT] != nullptr;
     const int kind = matrix ? kLoopMatrix : (large ? kLoopVectorTiled : kLoopVector);
     a.lds_spheres = lds_sphere_slots(a.scene.n_sph);
     const size_t lds_bytes = lds_fixed_bytes(kind) + sizeof(float4) * (size_t)a.lds_spheres +

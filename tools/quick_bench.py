@@ -28,6 +28,7 @@ ap.add_argument("--depth", type=int, default=50)
 ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--modes", default="fast,strict")
+ap.add_argument("--vector-loop", action="store_true", help="sphere filter on the vector unit (CASTER_HIP_VECTOR_LOOP)")
 args = ap.parse_args()
 
 if args.scene == "rtiow":
@@ -54,7 +55,7 @@ for mode in args.modes.split(","):
         gpu.memset_zero(acc, nbytes)
         gpu.synchronize()
         t0 = time.perf_counter()
-        gpu.render(cam, args.width, args.height, 0, args.spp, args.depth, 0xC0FFEE, acc, strict=strict)
+        gpu.render(cam, args.width, args.height, 0, args.spp, args.depth, 0xC0FFEE, acc, strict=strict, vector_loop=args.vector_loop)
         rays, ms = gpu.render_stats()
         wall = time.perf_counter() - t0
         flops = rays * (18 * ns + 12 * nr + 100)
