@@ -220,7 +220,7 @@ static int build_matrix_tables(caster_hip_ctx* ctx, const std::vector<float4>& s
     s.mfma_scale = 1.0f;
     const size_t n = sph.size();
     const size_t n_blocks = (n + 31) / 32;
-    if (n == 0 || n_blocks > (size_t)caster::kMfmaMaxBlocks) return CASTER_HIP_OK;
+    if (n == 0) return CASTER_HIP_OK;
     double extent = 0.0;
     for (size_t k = 0; k < n; ++k) {
         const float4 f = sph_filter[k];            // c'x, c'y, c'z, C - r*r (+inf: tested directly, -inf: huge but not listed)

@@ -27,7 +27,6 @@ constexpr float kFilterMarginFast = 2.5e-6f;
 // half-precision operands and of the matrix unit's accumulation to those margins.
 constexpr float kFilterMarginMfmaExtra = 3.0e-5f;
 constexpr int kMfmaMinSpheres = 33;   // below this the vector loop is as fast or faster (measured: equal at 32, 1.4 x slower at 256)
-constexpr int kMfmaMaxBlocks = 16;     // sphere blocks of 32 that a candidate list entry can name (5 bits, 31 is the end mark's)
 
 struct SceneDev {
     const float4* sph;       // cx, cy, cz, r            (list order among spheres)

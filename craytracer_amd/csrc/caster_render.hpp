@@ -606,7 +606,11 @@ struct MfmaLists {
     int cnt0, cnt1;         // entries this lane has written to the lists of its owners r and 32 + r
 };
 
-CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact, const Slot& sa, const Slot& sb,
+// base: first sphere of the tile of 16 blocks that the list entries count their blocks from.  The exact
+// operands of a candidate come from the tile's image in LDS, or (EXACT_LDS false: scenes larger than one
+// tile) from the sphere table in device memory.
+template <bool EXACT_LDS>
+CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact, int base, const Slot& sa, const Slot& sb,
                      float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
 {
     const unsigned long long t0 = tm.now();
@@ -640,7 +644,7 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
             // meta: bit 0 upper or lower eight registers, bits 1-5 block, bit 7 slot, bit 16 writer half;
             // bit b of the entry stands for register v = 8 * (meta & 1) + 7 - b, row 8 (v >> 2) + 4 half + (v & 3)
             const int v = (int)(meta & 1u) * 8 + 7 - b;
-            const int k = (int)((meta >> 1) & 31u) * 32 + (v >> 2) * 8 + (int)(meta >> 16) * 4 + (v & 3);
+            const int k = base + (int)((meta >> 1) & 31u) * 32 + (v >> 2) * 8 + (int)(meta >> 16) * 4 + (v & 3);
             const bool second = ((meta >> 7) & 1u) != 0;
             if (k < sc.n_sph) {
                 V3 o, d;
@@ -648,7 +652,7 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
                 d.x = second ? sb.d.x : sa.d.x; d.y = second ? sb.d.y : sa.d.y; d.z = second ? sb.d.z : sa.d.z;
                 const float aa = second ? sb.aa : sa.aa;
                 const float tmin = second ? sb.tmin : sa.tmin;
-                const float4 e = lds_exact[k];
+                const float4 e = EXACT_LDS ? lds_exact[k] : exact_image(sc.sph[k]);
                 float t;
                 if (candidate_root(e, o, d, aa, tmin, t)) {
                     float closest = second ? closestB : closestA;
@@ -669,8 +673,8 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
 // spheres in the lane's registers; a clear sign bit is a candidate.  The 16 signs are gathered
 // into a mask (one v_alignbit each) and a lane with candidates appends up to two list entries,
 // one per eight registers: slot << 15 | block << 9 | upper or lower eight << 8 | the eight bits.
-template <int CB>
-CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk, MfmaLists& ml,
+template <bool EXACT_LDS, int CB>
+CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk, int base, MfmaLists& ml,
                       const SceneView& sc, const float4* lds_exact, const Slot& sa, const Slot& sb,
                       float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
 {
@@ -685,7 +689,7 @@ CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int bl
         CASTER_STAT(12);
         int cnt = (CB & 1) ? ml.cnt1 : ml.cnt0;
         if (__any(cnt > kMfmaListCap - 2)) {
-            drain_mfma(ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+            drain_mfma<EXACT_LDS>(ml, sc, lds_exact, base, sa, sb, closestA, closestB, bestA, bestB, tm);
             cnt = 0;
         }
         const int lane = threadIdx.x & 63;
@@ -697,8 +701,11 @@ CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int bl
     }
 }
 
-// The sphere loop: all blocks of the table against the wave's four column blocks.  The table
-// holds one block more than the scene needs (read ahead).
+// The sphere loop: all blocks of the table against the wave's four column blocks, in tiles of
+// kMfmaTileBlocks blocks (the list entries name a block within its tile; the lists are worked off after
+// every tile).  The table holds one block more than the scene needs (read ahead).
+constexpr int kMfmaTileBlocks = kSphTile / 32;
+template <bool EXACT_LDS>
 CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks, const MfmaRays& mr, MfmaLists& ml,
                      const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
                      WaveTimers& tm)
@@ -706,16 +713,22 @@ CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks,
     const uint4* tab = sc.mfma_tab + (threadIdx.x & 63);
     uint4 a0 = tab[0], a1 = tab[64];
 #pragma unroll 1
-    for (int blk = 0; blk < n_blocks; ++blk) {
-        const uint4 n0 = tab[(blk + 1) * 128], n1 = tab[(blk + 1) * 128 + 64];
-        const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
-        mfma_column<0>(A0, A1, mr.b00, mr.b01, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-        mfma_column<1>(A0, A1, mr.b10, mr.b11, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-        mfma_column<2>(A0, A1, mr.b20, mr.b21, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-        mfma_column<3>(A0, A1, mr.b30, mr.b31, blk, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-        a0 = n0; a1 = n1;
+    for (int first = 0; first < n_blocks; first += kMfmaTileBlocks) {
+        const int last = first + kMfmaTileBlocks < n_blocks ? first + kMfmaTileBlocks : n_blocks;
+        const int base = first * 32;
+#pragma unroll 1
+        for (int blk = first; blk < last; ++blk) {
+            const uint4 n0 = tab[(blk + 1) * 128], n1 = tab[(blk + 1) * 128 + 64];
+            const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
+            const int in_tile = blk - first;
+            mfma_column<EXACT_LDS, 0>(A0, A1, mr.b00, mr.b01, in_tile, base, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+            mfma_column<EXACT_LDS, 1>(A0, A1, mr.b10, mr.b11, in_tile, base, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+            mfma_column<EXACT_LDS, 2>(A0, A1, mr.b20, mr.b21, in_tile, base, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+            mfma_column<EXACT_LDS, 3>(A0, A1, mr.b30, mr.b31, in_tile, base, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+            a0 = n0; a1 = n1;
+        }
+        drain_mfma<EXACT_LDS>(ml, sc, lds_exact, base, sa, sb, closestA, closestB, bestA, bestB, tm);
     }
-    drain_mfma(ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
 }
 
 // The spheres that are candidates for every ray (SceneDev::n_always of them) do not go through
@@ -863,8 +876,9 @@ CDEV void swap_slots(Slot& a, Slot& b)
 #endif
 // The sphere loop of a launch: the packed vector filter with the exact sphere image in LDS, the
 // same streaming the image through LDS in tiles (more than kSphTile spheres), or the matrix-core
-// filter with the exact image in LDS (scenes of up to kSphTile spheres that qualify).
-enum LoopKind { kLoopVector = 0, kLoopVectorTiled = 1, kLoopMatrix = 2 };
+// filter with the exact image in LDS (up to kSphTile spheres) or in device memory (more), for
+// scenes that qualify.
+enum LoopKind { kLoopVector = 0, kLoopVectorTiled = 1, kLoopMatrix = 2, kLoopMatrixLarge = 3 };
 constexpr int lds_fixed_bytes(int kind)
 {
     return (int)sizeof(unsigned long long) * kWaves * kAccStride +
@@ -872,12 +886,12 @@ constexpr int lds_fixed_bytes(int kind)
 }
 
 template <int KIND>
-__global__ __launch_bounds__(kBlock, KIND == kLoopMatrix ? CASTER_MATRIX_BLOCKS_PER_CU : CASTER_BLOCKS_PER_CU)
+__global__ __launch_bounds__(kBlock, KIND >= kLoopMatrix ? CASTER_MATRIX_BLOCKS_PER_CU : CASTER_BLOCKS_PER_CU)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
-    constexpr unsigned int kPerCU = KIND == kLoopMatrix ? CASTER_MATRIX_BLOCKS_PER_CU : CASTER_BLOCKS_PER_CU;
+    constexpr unsigned int kPerCU = KIND >= kLoopMatrix ? CASTER_MATRIX_BLOCKS_PER_CU : CASTER_BLOCKS_PER_CU;
     constexpr bool TILED = KIND == kLoopVectorTiled;
-    constexpr bool MATRIX = KIND == kLoopMatrix;
+    constexpr bool MATRIX = KIND >= kLoopMatrix;
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ AlwaysLds s_always;
     // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists (u16; [kWaves][kListCap][64], or
@@ -1003,7 +1017,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         test_always(&s_always, a.scene.n_always, sa, sb, closestA, closestB, bestA, bestB);
         if (MATRIX) {
             const MfmaRays mr = pack_rays_mfma(sa, sb, ref, a.scene.mfma_scale);
-            isect_mfma(sc, s_exact, a.scene.mfma_blocks, mr, ml, sa, sb, closestA, closestB, bestA, bestB, tm);
+            isect_mfma<KIND == kLoopMatrix>(sc, s_exact, a.scene.mfma_blocks, mr, ml, sa, sb, closestA, closestB, bestA, bestB, tm);
             non_finite_rule(mr.finiteA, sc.n_sph, closestA, bestA);
             non_finite_rule(mr.finiteB, sc.n_sph, closestB, bestB);
             tm.add(WaveTimers::kIntersect, t_isect);
@@ -1050,18 +1064,19 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     if (units <= 0 || units > 0x7fffffffLL) return hipErrorInvalidValue;
     a.n_units = (int)units;
     const bool large = a.scene.n_sph > kSphTile;
-    const bool matrix = !large && a.scene.n_sph >= kMfmaMinSpheres && a.scene.mfma_blocks > 0 && a.scene.mfma_tab[CASTER_STRICT] != nullptr;
-    const int kind = matrix ? kLoopMatrix : (large ? kLoopVectorTiled : kLoopVector);
-    a.lds_spheres = lds_sphere_slots(a.scene.n_sph);
+    const bool matrix = a.scene.n_sph >= kMfmaMinSpheres && a.scene.mfma_blocks > 0 && a.scene.mfma_tab[CASTER_STRICT] != nullptr;
+    const int kind = matrix ? (large ? kLoopMatrixLarge : kLoopMatrix) : (large ? kLoopVectorTiled : kLoopVector);
+    a.lds_spheres = kind == kLoopMatrixLarge ? 0 : lds_sphere_slots(a.scene.n_sph);
     const size_t lds_bytes = lds_fixed_bytes(kind) + sizeof(float4) * (size_t)a.lds_spheres +
                              (a.scene.noise_vec ? kNoiseLdsBytes : 0);
     long long blocks = (units + kWaves - 1) / kWaves;
     // resident_blocks counts CASTER_BLOCKS_PER_CU per CU
-    if (kind == kLoopMatrix) resident_blocks = resident_blocks / CASTER_BLOCKS_PER_CU * CASTER_MATRIX_BLOCKS_PER_CU;
+    if (kind >= kLoopMatrix) resident_blocks = resident_blocks / CASTER_BLOCKS_PER_CU * CASTER_MATRIX_BLOCKS_PER_CU;
     if (blocks > resident_blocks) blocks = resident_blocks;      // persistent: the waves loop over the queue
     const dim3 grid((unsigned)blocks), block(kBlock);
     switch (kind) {
     case kLoopMatrix: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopMatrix>, grid, block, lds_bytes, st, a); break;
+    case kLoopMatrixLarge: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopMatrixLarge>, grid, block, lds_bytes, st, a); break;
     case kLoopVectorTiled: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopVectorTiled>, grid, block, lds_bytes, st, a); break;
     default: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopVector>, grid, block, lds_bytes, st, a); break;
     }
@@ -1113,15 +1128,18 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
     cl.cnt = 0;
     WaveTimers tm;
     test_always(&s_always, sd.n_always, sl[0], sl[1], closest[0], closest[1], best[0], best[1]);
-    const bool matrix = sd.mfma_blocks > 0 && sc.mfma_tab != nullptr && sc.n_sph <= kSphTile;
+    const bool matrix = sd.mfma_blocks > 0 && sc.mfma_tab != nullptr;
     if (matrix) {
-        stage_spheres(s_exact, sc, 0, sc.n_sph);
+        if (sc.n_sph <= kSphTile) stage_spheres(s_exact, sc, 0, sc.n_sph);
         __syncthreads();
         MfmaLists ml;
         ml.mem = s_cand + (threadIdx.x >> 6) * kMfmaListWords;
         ml.cnt0 = ml.cnt1 = 0;
         const MfmaRays mr = pack_rays_mfma(sl[0], sl[1], ref, sd.mfma_scale);
-        isect_mfma(sc, s_exact, sd.mfma_blocks, mr, ml, sl[0], sl[1], closest[0], closest[1], best[0], best[1], tm);
+        if (sc.n_sph <= kSphTile)
+            isect_mfma<true>(sc, s_exact, sd.mfma_blocks, mr, ml, sl[0], sl[1], closest[0], closest[1], best[0], best[1], tm);
+        else
+            isect_mfma<false>(sc, s_exact, sd.mfma_blocks, mr, ml, sl[0], sl[1], closest[0], closest[1], best[0], best[1], tm);
     }
     for (int base = 0; base < (matrix ? 0 : sc.n_sph); base += kSphTile) {
         const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;

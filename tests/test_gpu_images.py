@@ -99,7 +99,7 @@ def test_fast_mode_is_scheduling_independent(gpu, ca):
     gpu.set_chunk(0)
 
 
-@pytest.mark.parametrize("name", ["rtiow", "perlin", "scene_0_textured", "stress_500", "offset"])
+@pytest.mark.parametrize("name", ["rtiow", "perlin", "scene_0_textured", "stress_500", "stress_1500", "offset"])
 def test_matrix_and_vector_loops_give_identical_frames(gpu, ca, name):
     """The conservative sphere filter runs on the matrix cores (half-precision pieces, a wider
     margin) where the scene qualifies and on the vector unit otherwise; either way the candidates go
@@ -114,6 +114,8 @@ def test_matrix_and_vector_loops_give_identical_frames(gpu, ca, name):
         fs = ca.scene_0(textured=True)
     elif name == "stress_500":
         fs = ca.scene_stress(500, 2)
+    elif name == "stress_1500":
+        fs = ca.scene_stress(1500, 2)                   # more than one tile of 512: exact operands from device memory
     else:
         fs = ca.scene_rtiow(5)                          # far from the origin: the filter's reference point and scale at work
         objs = fs.objects.copy()
