@@ -494,17 +494,14 @@ CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, 
 // column block, which is where the instruction wants them.  The result has the ray on the
 // lane and 16 spheres in the registers: rows 8(v >> 2) + 4h + (v & 3), v = 0..15.
 //
-// A lane that finds a candidate is not the lane that owns the ray.  It appends a 16-bit entry
-// (slot, block, register quad, four bits) to a list of the owner's in LDS: every owner has two
-// lists, one per half h of the wave, so each list has exactly one writer and needs no atomics.
-// After the loop (or when a list may run full) the writers end their lists with a mark and
-// every lane works off its own two lists with the reference's arithmetic (candidate_root).
+// A lane that finds a candidate is not the lane that owns the ray.  It appends the 16-bit mask of
+// its candidates to a list of the owner's in LDS: every owner has four lists, one per half of the
+// wave and slot, so each list has exactly one writer and needs no atomics (see MfmaLists).  After
+// every tile of blocks all lanes work off their own lists with the reference's arithmetic
+// (candidate_root).
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 
-constexpr int kMfmaListCap = 16;                                      // entries per list (one more slot holds the end mark)
-constexpr int kMfmaListWords = (kMfmaListCap + 1) * 2 * 64;           // u16 per wave
-constexpr unsigned int kMfmaEndMark = 0xFFFFu;
 #if CASTER_STRICT
 constexpr float kFilterMarginMfma = kFilterMarginStrict + kFilterMarginMfmaExtra;
 #else
@@ -601,14 +598,22 @@ CDEV MfmaRays pack_rays_mfma(const Slot& sa, const Slot& sb, const float3 ref, f
     return m;
 }
 
+// Candidate lists of the matrix loop.  The sphere blocks are worked through in tiles of
+// kMfmaTileBlocks; within a tile, the lane that evaluates column block CB meets each block once, so
+// a list -- (owner lane w, writer half h, slot s) -- takes at most one entry per block: the 16-bit
+// candidate mask itself.  Which blocks have an entry is a bitmap the writer keeps in a register and
+// hands over with the lists; nothing can overflow and nothing needs a count.
+// Layout (u16, per wave): entry p of list (w, h, s) at mem[(4p + 2h + s) * 64 + w], p < kMfmaTileBlocks; the
+// bitmaps in row p = kMfmaTileBlocks.
+constexpr int kMfmaTileBlocks = 8;
+constexpr int kMfmaListWords = (kMfmaTileBlocks + 1) * 4 * 64;         // u16 per wave
 struct MfmaLists {
-    unsigned short* mem;    // this wave's: entry p of the list (owner lane w, writer half h) at mem[(2p + h) * 64 + w]
-    int cnt0, cnt1;         // entries this lane has written to the lists of its owners r and 32 + r
+    unsigned short* mem;            // this wave's
+    unsigned int bm0, bm1, bm2, bm3;// blocks of the tile for which this lane has written an entry, per column block
 };
 
-// base: first sphere of the tile of 16 blocks that the list entries count their blocks from.  The exact
-// operands of a candidate come from the tile's image in LDS, or (EXACT_LDS false: scenes larger than one
-// tile) from the sphere table in device memory.
+// base: first sphere of the tile.  The exact operands of a candidate come from the scene's image in
+// LDS, or (EXACT_LDS false: scenes larger than that image) from the sphere table in device memory.
 template <bool EXACT_LDS>
 CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact, int base, const Slot& sa, const Slot& sb,
                      float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
@@ -616,36 +621,37 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
     const unsigned long long t0 = tm.now();
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5, r = lane & 31;
-    ml.mem[(2 * ml.cnt0 + h) * 64 + r] = (unsigned short)kMfmaEndMark;
-    ml.mem[(2 * ml.cnt1 + h) * 64 + 32 + r] = (unsigned short)kMfmaEndMark;
-    ml.cnt0 = ml.cnt1 = 0;
+    // column block CB belongs to owner 32 (CB & 1) + r and slot CB >> 1
+    unsigned short* maps = ml.mem + kMfmaTileBlocks * 256;
+    maps[(2 * h + 0) * 64 + r] = (unsigned short)ml.bm0;
+    maps[(2 * h + 0) * 64 + 32 + r] = (unsigned short)ml.bm1;
+    maps[(2 * h + 1) * 64 + r] = (unsigned short)ml.bm2;
+    maps[(2 * h + 1) * 64 + 32 + r] = (unsigned short)ml.bm3;
+    ml.bm0 = ml.bm1 = ml.bm2 = ml.bm3 = 0u;
     // LDS instructions of one wave complete in order: the reads below see the writes above
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int list = 0, pos = 0;
-    unsigned int bits = 0, meta = 0;
-    bool more = true;
+    // this lane's four lists: bitmap of list l in byte l
+    const unsigned int all = (unsigned int)maps[lane] | ((unsigned int)maps[64 + lane] << 8) |
+                             ((unsigned int)maps[128 + lane] << 16) | ((unsigned int)maps[192 + lane] << 24);
+    unsigned int todo = all, bits = 0u, where = 0u;
     for (;;) {
-        if (bits == 0 && more) {
-            const unsigned int e = ml.mem[(2 * pos + list) * 64 + lane];
-            if (e == kMfmaEndMark) {
-                if (list == 0) { list = 1; pos = 0; } else more = false;
-            } else {
-                ++pos;
-                bits = e & 0xFFu;
-                meta = (e >> 8) | ((unsigned int)list << 16);
-            }
+        if (bits == 0u && todo != 0u) {
+            where = (unsigned int)__builtin_ctz(todo);          // list in bits 3-4, block in bits 0-2
+            todo &= todo - 1u;
+            const unsigned int list = where >> 3;
+            const unsigned int before = (all >> (list * 8u)) & ((1u << (where & 7u)) - 1u);
+            bits = ml.mem[((unsigned int)__popc(before) * 4u + list) * 64u + (unsigned int)lane];
         }
-        if (!__any(bits != 0 || more)) break;
+        if (!__any(bits != 0u)) break;
         CASTER_STAT(1);
-        if (bits != 0) {
+        if (bits != 0u) {
             const int b = __builtin_ctz(bits);
             bits &= bits - 1u;
-            // meta: bit 0 upper or lower eight registers, bits 1-5 block, bit 7 slot, bit 16 writer half;
-            // bit b of the entry stands for register v = 8 * (meta & 1) + 7 - b, row 8 (v >> 2) + 4 half + (v & 3)
-            const int v = (int)(meta & 1u) * 8 + 7 - b;
-            const int k = base + (int)((meta >> 1) & 31u) * 32 + (v >> 2) * 8 + (int)(meta >> 16) * 4 + (v & 3);
-            const bool second = ((meta >> 7) & 1u) != 0;
+            // bit b stands for register v = 15 - b: row 8 (v >> 2) + 4 (writer half) + (v & 3) of the block
+            const int v = 15 - b;
+            const int k = base + (int)(where & 7u) * 32 + (v >> 2) * 8 + (int)(where >> 4) * 4 + (v & 3);
+            const bool second = ((where >> 3) & 1u) != 0u;
             if (k < sc.n_sph) {
                 V3 o, d;
                 o.x = second ? sb.o.x : sa.o.x; o.y = second ? sb.o.y : sa.o.y; o.z = second ? sb.o.z : sa.o.z;
@@ -671,40 +677,32 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
 
 // One column block against one sphere block: two matrix instructions leave key - threshold of 16
 // spheres in the lane's registers; a clear sign bit is a candidate.  The 16 signs are gathered
-// into a mask (one v_alignbit each) and a lane with candidates appends up to two list entries,
-// one per eight registers: slot << 15 | block << 9 | upper or lower eight << 8 | the eight bits.
-template <bool EXACT_LDS, int CB>
-CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk, int base, MfmaLists& ml,
-                      const SceneView& sc, const float4* lds_exact, const Slot& sa, const Slot& sb,
-                      float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
+// into a mask (one v_alignbit each; register v in bit 15 - v) and a lane with candidates appends the
+// mask to the list of the ray's owner.
+template <int CB>
+CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk /* in the tile */, MfmaLists& ml)
 {
     f16x acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
-    unsigned int neg = 0u;          // register v ends up in bit 15 - v
+    unsigned int neg = 0u;
 #pragma unroll
     for (int v = 0; v < 16; ++v) neg = push_sign(neg, acc[v]);
     const unsigned int cand = ~neg & 0xFFFFu;
-    if (__any(cand != 0u)) {
+    if (cand != 0u) {
         CASTER_STAT(12);
-        int cnt = (CB & 1) ? ml.cnt1 : ml.cnt0;
-        if (__any(cnt > kMfmaListCap - 2)) {
-            drain_mfma<EXACT_LDS>(ml, sc, lds_exact, base, sa, sb, closestA, closestB, bestA, bestB, tm);
-            cnt = 0;
-        }
         const int lane = threadIdx.x & 63;
-        unsigned short* dst = ml.mem + (lane >> 5) * 64 + (CB & 1) * 32 + (lane & 31);
-        const unsigned int head = ((unsigned int)(CB >> 1) << 15) | ((unsigned int)blk << 9);
-        if (cand & 0xFF00u) { dst[cnt * 128] = (unsigned short)(head | (cand >> 8)); ++cnt; }
-        if (cand & 0x00FFu) { dst[cnt * 128] = (unsigned short)(head | 0x100u | (cand & 0xFFu)); ++cnt; }
-        if (CB & 1) ml.cnt1 = cnt; else ml.cnt0 = cnt;
+        unsigned int& bm = CB == 0 ? ml.bm0 : CB == 1 ? ml.bm1 : CB == 2 ? ml.bm2 : ml.bm3;
+        // list (owner 32 (CB & 1) + (lane & 31), half lane >> 5, slot CB >> 1), next free entry
+        ml.mem[((unsigned int)__popc(bm) * 4u + 2u * (unsigned int)(lane >> 5) + (unsigned int)(CB >> 1)) * 64u +
+               (unsigned int)((CB & 1) * 32 + (lane & 31))] = (unsigned short)cand;
+        bm |= 1u << blk;
     }
 }
 
-// The sphere loop: all blocks of the table against the wave's four column blocks, in tiles of
-// kMfmaTileBlocks blocks (the list entries name a block within its tile; the lists are worked off after
-// every tile).  The table holds one block more than the scene needs (read ahead).
-constexpr int kMfmaTileBlocks = kSphTile / 32;
+// The sphere loop: all blocks of the table against the wave's four column blocks, tile by tile; the
+// lists are worked off after every tile.  The table holds one block more than the scene needs (read
+// ahead).
 template <bool EXACT_LDS>
 CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks, const MfmaRays& mr, MfmaLists& ml,
                      const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
@@ -715,19 +713,18 @@ CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks,
 #pragma unroll 1
     for (int first = 0; first < n_blocks; first += kMfmaTileBlocks) {
         const int last = first + kMfmaTileBlocks < n_blocks ? first + kMfmaTileBlocks : n_blocks;
-        const int base = first * 32;
 #pragma unroll 1
         for (int blk = first; blk < last; ++blk) {
             const uint4 n0 = tab[(blk + 1) * 128], n1 = tab[(blk + 1) * 128 + 64];
             const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
             const int in_tile = blk - first;
-            mfma_column<EXACT_LDS, 0>(A0, A1, mr.b00, mr.b01, in_tile, base, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-            mfma_column<EXACT_LDS, 1>(A0, A1, mr.b10, mr.b11, in_tile, base, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-            mfma_column<EXACT_LDS, 2>(A0, A1, mr.b20, mr.b21, in_tile, base, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
-            mfma_column<EXACT_LDS, 3>(A0, A1, mr.b30, mr.b31, in_tile, base, ml, sc, lds_exact, sa, sb, closestA, closestB, bestA, bestB, tm);
+            mfma_column<0>(A0, A1, mr.b00, mr.b01, in_tile, ml);
+            mfma_column<1>(A0, A1, mr.b10, mr.b11, in_tile, ml);
+            mfma_column<2>(A0, A1, mr.b20, mr.b21, in_tile, ml);
+            mfma_column<3>(A0, A1, mr.b30, mr.b31, in_tile, ml);
             a0 = n0; a1 = n1;
         }
-        drain_mfma<EXACT_LDS>(ml, sc, lds_exact, base, sa, sb, closestA, closestB, bestA, bestB, tm);
+        drain_mfma<EXACT_LDS>(ml, sc, lds_exact, first * 32, sa, sb, closestA, closestB, bestA, bestB, tm);
     }
 }
 
@@ -938,7 +935,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     cl.cnt = 0;
     MfmaLists ml;
     ml.mem = s_cand + wave * kMfmaListWords;
-    ml.cnt0 = ml.cnt1 = 0;
+    ml.bm0 = ml.bm1 = ml.bm2 = ml.bm3 = 0u;
     WaveTimers tm;
     tm.start();
     const unsigned long long t_begin = tm.now();
@@ -1134,7 +1131,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
         __syncthreads();
         MfmaLists ml;
         ml.mem = s_cand + (threadIdx.x >> 6) * kMfmaListWords;
-        ml.cnt0 = ml.cnt1 = 0;
+        ml.bm0 = ml.bm1 = ml.bm2 = ml.bm3 = 0u;
         const MfmaRays mr = pack_rays_mfma(sl[0], sl[1], ref, sd.mfma_scale);
         if (sc.n_sph <= kSphTile)
             isect_mfma<true>(sc, s_exact, sd.mfma_blocks, mr, ml, sl[0], sl[1], closest[0], closest[1], best[0], best[1], tm);
