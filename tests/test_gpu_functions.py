@@ -286,7 +286,7 @@ def _grazing_rays(rng, fs, n):
     return np.concatenate([o, d], axis=1).astype(np.float32)
 
 
-@pytest.mark.parametrize("scene_name", ["rtiow", "stress_2600", "scene_0", "offset_scene"])
+@pytest.mark.parametrize("scene_name", ["rtiow", "stress_2600", "scene_0", "offset_scene", "mixed_scales"])
 def test_production_sphere_loop_parity(gpu, orc, ca, scene_name):
     """hit_list_hit_all through the render kernel's own loop (LDS tiles, candidate filter, packed slots):
     every hit/miss decision, object and t must equal the reference arithmetic, in particular where the
@@ -298,6 +298,17 @@ def test_production_sphere_loop_parity(gpu, orc, ca, scene_name):
         fs = ca.scene_stress(2600, 2)                      # three LDS tiles
     elif scene_name == "scene_0":
         fs = ca.scene_0()
+    elif scene_name == "mixed_scales":
+        # radii over a factor of 30 (more would make the large ones "always candidates"), centres spread
+        # over 80 units: the half-precision operands of the matrix filter at their widest range
+        fs = ca.scene_stress(400, 7)
+        objs = fs.objects.copy()
+        small = objs["g"][:, 3] < 50
+        k = int(small.sum())
+        objs["g"][small, 3] = np.exp(rng.uniform(np.log(0.01), np.log(0.3), size=k)).astype(np.float32)
+        objs["g"][small, 0] = rng.uniform(-40, 40, size=k).astype(np.float32)
+        objs["g"][small, 2] = rng.uniform(-40, 40, size=k).astype(np.float32)
+        fs = ca.FlatScene(objs, fs.materials, [])
     else:
         fs = ca.scene_rtiow(5)                             # the whole scene far from the origin
         objs = fs.objects.copy()
@@ -311,6 +322,14 @@ def test_production_sphere_loop_parity(gpu, orc, ca, scene_name):
     if scene_name == "offset_scene":
         rays[:, 0] += 3000.0
         rays[:, 2] -= 1500.0
+    # rays from very far away, aimed at spheres: beyond the range of the matrix filter's half-precision
+    # operands, which must then hand every sphere to the exact test
+    far = rng.choice(n - 1, size=400, replace=False)
+    tgt = rays[far, :3] + rays[far, 3:] * 0.5
+    dirs = rng.normal(size=(400, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dist = np.exp(rng.uniform(np.log(3e3), np.log(3e6), size=(400, 1)))
+    rays[far, :3] = (tgt - dirs * dist).astype(np.float32)
+    rays[far, 3:] = (dirs * rng.uniform(0.1, 3.0, size=(400, 1))).astype(np.float32)
     rays[-1] = [np.nan, 0, 0, 0, 1, 0]                     # non-finite ray: NaN passes every range test (src/caster.c:107,114)
     g = gpu.test_trace(rays, strict=True)
     # the filter on the vector unit and on the matrix cores hands the same candidates to the same exact test
