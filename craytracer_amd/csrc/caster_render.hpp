@@ -8,9 +8,11 @@
 //     per unit) until it is empty; a 256-thread block holds four waves that
 //     share one copy of the sphere list in LDS (the operands of the exact test);
 //   * every lane carries TWO path slots, so a wave traces 128 rays per loop
-//     trip and the sphere test runs on packed FP32 (v_pk_*_f32: slot A in the
-//     low half, slot B in the high half) with the sphere's numbers as scalar
-//     operands, loaded through the scalar cache;
+//     trip.  The conservative sphere test is a 32 x 32 matrix product per 32
+//     spheres and 32 rays on the matrix cores (v_mfma_f32_32x32x16_f16, see "sphere
+//     loop on the matrix cores"); small scenes and scenes that do not qualify run
+//     it on packed FP32 (v_pk_*_f32: slot A in the low half, slot B in the high
+//     half) with the sphere's numbers as scalar operands from the scalar cache;
 //   * when a path ends, its radiance is added to the accumulator of the wave's
 //     current tile in LDS and the slot takes the next (pixel, sample) of the
 //     unit's pool: the finished slots are found with a ballot and numbered with
@@ -27,9 +29,8 @@
 //     integer atomics); a later kernel converts it to float once.
 //
 // Every ray is tested against every sphere (src/caster.c:204 has no early
-// out): the loop evaluates a conservative candidate test for both slots
-// branch-free, notes the few candidates in per-lane lists and runs the
-// reference's root arithmetic on those after the loop.
+// out): the loop evaluates a conservative candidate test, notes the few
+// candidates in lists in LDS and runs the reference's root arithmetic on those.
 #pragma once
 
 #include "caster_device.hpp"
