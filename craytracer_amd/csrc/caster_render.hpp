@@ -495,11 +495,9 @@ CDEV void isect_tile(const SphereLds lds, int cnt, int base, const PairRays& r, 
 // column block, which is where the instruction wants them.  The result has the ray on the
 // lane and 16 spheres in the registers: rows 8(v >> 2) + 4h + (v & 3), v = 0..15.
 //
-// A lane that finds a candidate is not the lane that owns the ray.  It appends the 16-bit mask of
-// its candidates to a list of the owner's in LDS: every owner has four lists, one per half of the
-// wave and slot, so each list has exactly one writer and needs no atomics (see MfmaLists).  After
-// every tile of blocks all lanes work off their own lists with the reference's arithmetic
-// (candidate_root).
+// A lane that finds a candidate is not the lane that owns the ray, and the candidates are spread
+// unevenly over the rays: they go to a queue of the wave and are worked off by all lanes together
+// (see MfmaQueue).
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 
@@ -599,78 +597,103 @@ CDEV MfmaRays pack_rays_mfma(const Slot& sa, const Slot& sb, const float3 ref, f
     return m;
 }
 
-// Candidate lists of the matrix loop.  The sphere blocks are worked through in tiles of
-// kMfmaTileBlocks; within a tile, the lane that evaluates column block CB meets each block once, so
-// a list -- (owner lane w, writer half h, slot s) -- takes at most one entry per block: the 16-bit
-// candidate mask itself.  Which blocks have an entry is a bitmap the writer keeps in a register and
-// hands over with the lists; nothing can overflow and nothing needs a count.
-// Layout (u16, per wave): entry p of list (w, h, s) at mem[(4p + 2h + s) * 64 + w], p < kMfmaTileBlocks; the
-// bitmaps in row p = kMfmaTileBlocks.
-constexpr int kMfmaTileBlocks = 8;
-constexpr int kMfmaListWords = (kMfmaTileBlocks + 1) * 4 * 64;         // u16 per wave
-struct MfmaLists {
-    unsigned short* mem;            // this wave's
-    unsigned int bm0, bm1, bm2, bm3;// blocks of the tile for which this lane has written an entry, per column block
+// Candidates of the matrix loop.  A lane that finds candidates in a column block appends one entry --
+// whose ray, which block, the 16-bit mask -- to a queue of the WAVE in LDS (the position comes from a
+// ballot, no atomics).  The queue is worked off by all lanes together, 64 entries at a time: a lane
+// takes an entry, fetches the ray from its owner's registers (ds_bpermute), runs the reference's
+// arithmetic (candidate_root) on the entry's spheres and merges a hit into the owner's result in LDS
+// with a 64-bit atomic maximum over (~t, sphere + 1): the smallest t and, among equal ones, the latest
+// sphere -- what take_hit does.  A ray with many candidates thus costs the wave no more than a ray with
+// one: the work is spread over the lanes.
+//
+// Entry: bits 0-15 mask (register v in bit 15 - v), 16-22 block within the tile, 23-27 ray r of the
+// column block, 28 column block & 1 (owner lane = 32 * that + r), 29 slot, 30 writer half h (rows
+// 8 (v >> 2) + 4 h + (v & 3) of the block).
+constexpr int kMfmaTileBlocks = 128;        // blocks per tile (7 bits in an entry)
+constexpr int kMfmaQueueCap = 512;          // entries; one block of 32 spheres adds 256 at most
+constexpr int kMfmaQueueBytes = kMfmaQueueCap * 4 + 128 * 8;       // per wave: the queue and the 128 results
+struct MfmaQueue {
+    unsigned int* entries;          // this wave's [kMfmaQueueCap]
+    unsigned long long* result;     // this wave's [128]: slot * 64 + lane
+    int count;                      // wave-uniform
 };
+
+CDEV unsigned long long hit_key(float t, int index)
+{
+    return ((unsigned long long)(~__float_as_uint(t)) << 32) | (unsigned long long)(unsigned int)(index + 1);
+}
+
+// Before the loop: the results start from what the directly tested spheres gave.
+CDEV void queue_begin(MfmaQueue& q, float closestA, float closestB, int bestA, int bestB)
+{
+    const int lane = threadIdx.x & 63;
+    q.result[lane] = hit_key(closestA, bestA);
+    q.result[64 + lane] = hit_key(closestB, bestB);
+    q.count = 0;
+}
+
+// After the last drain: every lane takes its two results back.
+CDEV void queue_end(const MfmaQueue& q, float& closestA, float& closestB, int& bestA, int& bestB)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long ka = q.result[lane], kb = q.result[64 + lane];
+    closestA = __uint_as_float(~(unsigned int)(ka >> 32)); bestA = (int)(unsigned int)ka - 1;
+    closestB = __uint_as_float(~(unsigned int)(kb >> 32)); bestB = (int)(unsigned int)kb - 1;
+}
+
+CDEV float fetch(int from, float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(from << 2, __float_as_int(x))); }
 
 // base: first sphere of the tile.  The exact operands of a candidate come from the scene's image in
 // LDS, or (EXACT_LDS false: scenes larger than that image) from the sphere table in device memory.
 template <bool EXACT_LDS>
-CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact, int base, const Slot& sa, const Slot& sb,
-                     float& closestA, float& closestB, int& bestA, int& bestB, WaveTimers& tm)
+CDEV void drain_mfma(MfmaQueue& q, const SceneView& sc, const float4* lds_exact, int base, const Slot& sa, const Slot& sb,
+                     WaveTimers& tm)
 {
     const unsigned long long t0 = tm.now();
     const int lane = threadIdx.x & 63;
-    const int h = lane >> 5, r = lane & 31;
-    // column block CB belongs to owner 32 (CB & 1) + r and slot CB >> 1
-    unsigned short* maps = ml.mem + kMfmaTileBlocks * 256;
-    maps[(2 * h + 0) * 64 + r] = (unsigned short)ml.bm0;
-    maps[(2 * h + 0) * 64 + 32 + r] = (unsigned short)ml.bm1;
-    maps[(2 * h + 1) * 64 + r] = (unsigned short)ml.bm2;
-    maps[(2 * h + 1) * 64 + 32 + r] = (unsigned short)ml.bm3;
-    ml.bm0 = ml.bm1 = ml.bm2 = ml.bm3 = 0u;
-    // LDS instructions of one wave complete in order: the reads below see the writes above
+    // LDS instructions of one wave complete in order: the reads below see the queue as written
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // this lane's four lists: bitmap of list l in byte l
-    const unsigned int all = (unsigned int)maps[lane] | ((unsigned int)maps[64 + lane] << 8) |
-                             ((unsigned int)maps[128 + lane] << 16) | ((unsigned int)maps[192 + lane] << 24);
-    unsigned int todo = all, bits = 0u, where = 0u;
-    for (;;) {
-        if (bits == 0u && todo != 0u) {
-            where = (unsigned int)__builtin_ctz(todo);          // list in bits 3-4, block in bits 0-2
-            todo &= todo - 1u;
-            const unsigned int list = where >> 3;
-            const unsigned int before = (all >> (list * 8u)) & ((1u << (where & 7u)) - 1u);
-            bits = ml.mem[((unsigned int)__popc(before) * 4u + list) * 64u + (unsigned int)lane];
+#pragma unroll 1
+    for (int first = 0; first < q.count; first += 64) {
+        const unsigned int e = (first + lane < q.count) ? q.entries[first + lane] : 0u;
+        unsigned int bits = e & 0xFFFFu;
+        const int owner = (int)((e >> 23) & 63u);           // ray r and the column block's parity
+        const bool second = ((e >> 29) & 1u) != 0u;
+        // the ray: every lane reads its owner's registers (all lanes take part in a ds_bpermute)
+        V3 o, d;
+        {
+            const float ax = fetch(owner, sa.o.x), ay = fetch(owner, sa.o.y), az = fetch(owner, sa.o.z);
+            const float bx = fetch(owner, sb.o.x), by = fetch(owner, sb.o.y), bz = fetch(owner, sb.o.z);
+            o.x = second ? bx : ax; o.y = second ? by : ay; o.z = second ? bz : az;
         }
-        if (!__any(bits != 0u)) break;
-        CASTER_STAT(1);
-        if (bits != 0u) {
-            const int b = __builtin_ctz(bits);
-            bits &= bits - 1u;
-            // bit b stands for register v = 15 - b: row 8 (v >> 2) + 4 (writer half) + (v & 3) of the block
-            const int v = 15 - b;
-            const int k = base + (int)(where & 7u) * 32 + (v >> 2) * 8 + (int)(where >> 4) * 4 + (v & 3);
-            const bool second = ((where >> 3) & 1u) != 0u;
-            if (k < sc.n_sph) {
-                V3 o, d;
-                o.x = second ? sb.o.x : sa.o.x; o.y = second ? sb.o.y : sa.o.y; o.z = second ? sb.o.z : sa.o.z;
-                d.x = second ? sb.d.x : sa.d.x; d.y = second ? sb.d.y : sa.d.y; d.z = second ? sb.d.z : sa.d.z;
-                const float aa = second ? sb.aa : sa.aa;
-                const float tmin = second ? sb.tmin : sa.tmin;
-                const float4 e = EXACT_LDS ? lds_exact[k] : exact_image(sc.sph[k]);
-                float t;
-                if (candidate_root(e, o, d, aa, tmin, t)) {
-                    float closest = second ? closestB : closestA;
-                    int best = second ? bestB : bestA;
-                    take_hit(t, k, closest, best);
-                    closestA = second ? closestA : closest; bestA = second ? bestA : best;
-                    closestB = second ? closest : closestB; bestB = second ? best : bestB;
+        {
+            const float ax = fetch(owner, sa.d.x), ay = fetch(owner, sa.d.y), az = fetch(owner, sa.d.z);
+            const float bx = fetch(owner, sb.d.x), by = fetch(owner, sb.d.y), bz = fetch(owner, sb.d.z);
+            d.x = second ? bx : ax; d.y = second ? by : ay; d.z = second ? bz : az;
+        }
+        const float aa_a = fetch(owner, sa.aa), aa_b = fetch(owner, sb.aa);
+        const float tm_a = fetch(owner, sa.tmin), tm_b = fetch(owner, sb.tmin);
+        const float aa = second ? aa_b : aa_a;
+        const float tmin = second ? tm_b : tm_a;
+        unsigned long long* dst = q.result + (second ? 64 : 0) + owner;
+        const int row0 = base + (int)((e >> 16) & 127u) * 32 + (int)((e >> 30) & 1u) * 4;
+        while (__any(bits != 0u)) {
+            CASTER_STAT(1);
+            if (bits != 0u) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                const int v = 15 - b;
+                const int k = row0 + (v >> 2) * 8 + (v & 3);
+                if (k < sc.n_sph) {
+                    const float4 ex = EXACT_LDS ? lds_exact[k] : exact_image(sc.sph[k]);
+                    float t;
+                    if (candidate_root(ex, o, d, aa, tmin, t)) atomicMax(dst, hit_key(t, k));
                 }
             }
         }
     }
+    q.count = 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     tm.add(WaveTimers::kLists, t0);
@@ -678,10 +701,10 @@ CDEV void drain_mfma(MfmaLists& ml, const SceneView& sc, const float4* lds_exact
 
 // One column block against one sphere block: two matrix instructions leave key - threshold of 16
 // spheres in the lane's registers; a clear sign bit is a candidate.  The 16 signs are gathered
-// into a mask (one v_alignbit each; register v in bit 15 - v) and a lane with candidates appends the
-// mask to the list of the ray's owner.
+// into a mask (one v_alignbit each; register v in bit 15 - v) and the lanes with candidates append
+// their entries to the wave's queue.
 template <int CB>
-CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk /* in the tile */, MfmaLists& ml)
+CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk /* in the tile */, MfmaQueue& q)
 {
     f16x acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
@@ -690,43 +713,51 @@ CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int bl
 #pragma unroll
     for (int v = 0; v < 16; ++v) neg = push_sign(neg, acc[v]);
     const unsigned int cand = ~neg & 0xFFFFu;
-    if (cand != 0u) {
+    const unsigned long long hits = __ballot(cand != 0u);
+    if (hits != 0ull) {
         CASTER_STAT(12);
-        const int lane = threadIdx.x & 63;
-        unsigned int& bm = CB == 0 ? ml.bm0 : CB == 1 ? ml.bm1 : CB == 2 ? ml.bm2 : ml.bm3;
-        // list (owner 32 (CB & 1) + (lane & 31), half lane >> 5, slot CB >> 1), next free entry
-        ml.mem[((unsigned int)__popc(bm) * 4u + 2u * (unsigned int)(lane >> 5) + (unsigned int)(CB >> 1)) * 64u +
-               (unsigned int)((CB & 1) * 32 + (lane & 31))] = (unsigned short)cand;
-        bm |= 1u << blk;
+        if (cand != 0u) {
+            const unsigned int lane = threadIdx.x & 63u;
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
+            // ray r = lane & 31, parity and slot of the column block, writer half
+            const unsigned int head = ((lane & 31u) << 23) | ((unsigned int)(CB & 1) << 28) | ((unsigned int)(CB >> 1) << 29) |
+                                      ((lane >> 5) << 30);
+            q.entries[(unsigned int)q.count + rank] = head | ((unsigned int)blk << 16) | cand;
+        }
+        q.count += __popcll(hits);
     }
 }
 
-// The sphere loop: all blocks of the table against the wave's four column blocks, tile by tile; the
-// lists are worked off after every tile.  The table holds one block more than the scene needs (read
+// The sphere loop: all blocks of the table against the wave's four column blocks.  The queue is
+// worked off when the next block might not fit, at the end of a tile of blocks (an entry names a
+// block within its tile) and at the end.  The table holds one block more than the scene needs (read
 // ahead).
 template <bool EXACT_LDS>
-CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks, const MfmaRays& mr, MfmaLists& ml,
+CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks, const MfmaRays& mr, MfmaQueue& q,
                      const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
                      WaveTimers& tm)
 {
+    queue_begin(q, closestA, closestB, bestA, bestB);
     const uint4* tab = sc.mfma_tab + (threadIdx.x & 63);
     uint4 a0 = tab[0], a1 = tab[64];
+    int base = 0;
 #pragma unroll 1
-    for (int first = 0; first < n_blocks; first += kMfmaTileBlocks) {
-        const int last = first + kMfmaTileBlocks < n_blocks ? first + kMfmaTileBlocks : n_blocks;
-#pragma unroll 1
-        for (int blk = first; blk < last; ++blk) {
-            const uint4 n0 = tab[(blk + 1) * 128], n1 = tab[(blk + 1) * 128 + 64];
-            const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
-            const int in_tile = blk - first;
-            mfma_column<0>(A0, A1, mr.b00, mr.b01, in_tile, ml);
-            mfma_column<1>(A0, A1, mr.b10, mr.b11, in_tile, ml);
-            mfma_column<2>(A0, A1, mr.b20, mr.b21, in_tile, ml);
-            mfma_column<3>(A0, A1, mr.b30, mr.b31, in_tile, ml);
-            a0 = n0; a1 = n1;
+    for (int blk = 0; blk < n_blocks; ++blk) {
+        const uint4 n0 = tab[(blk + 1) * 128], n1 = tab[(blk + 1) * 128 + 64];
+        const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
+        const int in_tile = blk & (kMfmaTileBlocks - 1);
+        if (q.count > kMfmaQueueCap - 256 || (in_tile == 0 && blk != 0)) {
+            drain_mfma<EXACT_LDS>(q, sc, lds_exact, base, sa, sb, tm);
+            base = (blk - in_tile) * 32;
         }
-        drain_mfma<EXACT_LDS>(ml, sc, lds_exact, first * 32, sa, sb, closestA, closestB, bestA, bestB, tm);
+        mfma_column<0>(A0, A1, mr.b00, mr.b01, in_tile, q);
+        mfma_column<1>(A0, A1, mr.b10, mr.b11, in_tile, q);
+        mfma_column<2>(A0, A1, mr.b20, mr.b21, in_tile, q);
+        mfma_column<3>(A0, A1, mr.b30, mr.b31, in_tile, q);
+        a0 = n0; a1 = n1;
     }
+    drain_mfma<EXACT_LDS>(q, sc, lds_exact, base, sa, sb, tm);
+    queue_end(q, closestA, closestB, bestA, bestB);
 }
 
 // The spheres that are candidates for every ray (SceneDev::n_always of them) do not go through
@@ -880,7 +911,7 @@ enum LoopKind { kLoopVector = 0, kLoopVectorTiled = 1, kLoopMatrix = 2, kLoopMat
 constexpr int lds_fixed_bytes(int kind)
 {
     return (int)sizeof(unsigned long long) * kWaves * kAccStride +
-           2 * kWaves * (kind >= kLoopMatrix ? kMfmaListWords : kListCap * 64);
+           kWaves * (kind >= kLoopMatrix ? kMfmaQueueBytes : 2 * kListCap * 64);
 }
 
 template <int KIND>
@@ -893,7 +924,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ AlwaysLds s_always;
     // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists (u16; [kWaves][kListCap][64], or
-    // [kWaves][kMfmaListWords] for the matrix loop), the exact sphere image of one tile, the noise tables
+    // the results and the queues of MfmaQueue for the matrix loop), the exact sphere image of one tile, the noise tables
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
     unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * kAccStride);
     float4* s_exact = reinterpret_cast<float4*>(s_dyn + lds_fixed_bytes(KIND));
@@ -934,9 +965,10 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     CandLists cl;
     cl.mem = s_cand + wave * kListCap * 64 + lane;
     cl.cnt = 0;
-    MfmaLists ml;
-    ml.mem = s_cand + wave * kMfmaListWords;
-    ml.bm0 = ml.bm1 = ml.bm2 = ml.bm3 = 0u;
+    MfmaQueue ml;
+    ml.result = reinterpret_cast<unsigned long long*>(s_cand) + wave * 128;
+    ml.entries = reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned long long*>(s_cand) + kWaves * 128) + wave * kMfmaQueueCap;
+    ml.count = 0;
     WaveTimers tm;
     tm.start();
     const unsigned long long t_begin = tm.now();
@@ -1089,7 +1121,7 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
                                 float* n3, int32_t* face, int32_t* mat)
 {
     __shared__ float4 s_exact[kSphTile + 2 * kLdsSlack];
-    __shared__ unsigned short s_cand[kWaves * kMfmaListWords];      // the larger of the two loops' lists
+    __shared__ __align__(8) unsigned short s_cand[kWaves * kMfmaQueueBytes / 2];      // the larger of the two loops' lists
     __shared__ AlwaysLds s_always;
     stage_always(&s_always, sd);
     __syncthreads();
@@ -1130,9 +1162,10 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
     if (matrix) {
         if (sc.n_sph <= kSphTile) stage_spheres(s_exact, sc, 0, sc.n_sph);
         __syncthreads();
-        MfmaLists ml;
-        ml.mem = s_cand + (threadIdx.x >> 6) * kMfmaListWords;
-        ml.bm0 = ml.bm1 = ml.bm2 = ml.bm3 = 0u;
+        MfmaQueue ml;
+        ml.result = reinterpret_cast<unsigned long long*>(s_cand) + (threadIdx.x >> 6) * 128;
+        ml.entries = reinterpret_cast<unsigned int*>(reinterpret_cast<unsigned long long*>(s_cand) + kWaves * 128) + (threadIdx.x >> 6) * kMfmaQueueCap;
+        ml.count = 0;
         const MfmaRays mr = pack_rays_mfma(sl[0], sl[1], ref, sd.mfma_scale);
         if (sc.n_sph <= kSphTile)
             isect_mfma<true>(sc, s_exact, sd.mfma_blocks, mr, ml, sl[0], sl[1], closest[0], closest[1], best[0], best[1], tm);
