@@ -255,3 +255,26 @@ def test_fast_mode_statistically_equal(gpu, orc, ca):
     # glass spheres, where the sign of a discriminant near zero depends on the rounding.
     assert abs(rs - rf) / rs < 2e-2
     assert mae < 1 / 255 and psnr > 45, (mae, psnr)
+
+
+def test_full_size_frame_properties(gpu, orc, ca):
+    """The benchmark frame at its full size (1920x1080, the 487-sphere scene, depth 50) with few
+    samples, checked through what does not depend on the size: both sphere loops give the same bits,
+    a split of the sample range adds up with equal ray counts, every pixel holds its sample count,
+    and rows taken from the bottom, the horizon and the top equal the restatement's to the image bar."""
+    fs = ca.scene_rtiow(1)
+    gpu.upload_scene(fs)
+    w, h, spp, depth, seed = 1920, 1080, 4, 50, 20240607
+    cam = ca.default_camera(w / h)
+    m, m_rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
+    v, v_rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True, vector_loop=True)
+    assert m_rays == v_rays and np.array_equal(m, v)
+    assert np.all(m[..., 3] == spp) and np.isfinite(m).all() and (m[..., :3] >= 0).all()
+    a, ra, _ = gpu.render_image(cam, w, h, 1, depth, seed, strict=True)
+    b, rb, _ = gpu.render_image(cam, w, h, spp - 1, depth, seed, strict=True, sample_begin=1)
+    assert ra + rb == m_rays
+    assert np.allclose((a + b)[..., :3], m[..., :3], rtol=2e-6, atol=1e-7)
+    sc = orc.Scene.from_flat(fs)
+    for j0 in (0, 430, 1078):
+        o, _ = orc.render(sc, cam, w, h, spp, depth, seed, rows=(j0, j0 + 2))
+        _assert_image_close(m[j0:j0 + 2], o[j0:j0 + 2], spp)
