@@ -267,11 +267,13 @@ static int build_matrix_tables(caster_hip_ctx* ctx, const std::vector<float4>& s
             }
             slot[29] = slot[30] = slot[31] = (_Float16)1024.0f;   // against the three halves of -threshold / 1024
             (void)sph_scale;
+            // The table holds the NEGATED operand: the product is then threshold - key, and a set
+            // sign bit marks a candidate (the kernel gathers sign bits; no complement needed).
             const size_t blk = k / 32, r = k % 32;
             for (int q = 0; q < 2; ++q)
                 for (int h = 0; h < 2; ++h)
                     for (int j = 0; j < 8; ++j)
-                        tab[(((blk * 2 + q) * 64) + (size_t)h * 32 + r) * 8 + j] = slot[16 * q + 8 * h + j];
+                        tab[(((blk * 2 + q) * 64) + (size_t)h * 32 + r) * 8 + j] = -slot[16 * q + 8 * h + j];
         }
         static_assert(sizeof(_Float16) == 2, "half size");
         std::vector<uint4> img(tab.size() / 8);

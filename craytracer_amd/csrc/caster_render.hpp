@@ -616,6 +616,7 @@ struct MfmaQueue {
     unsigned int* entries;          // this wave's [kMfmaQueueCap]
     unsigned long long* result;     // this wave's [128]: slot * 64 + lane
     int count;                      // wave-uniform
+    unsigned int head;              // this lane's part of an entry: ray r = lane & 31 in bits 23-27, writer half in bit 30
 };
 
 CDEV unsigned long long hit_key(float t, int index)
@@ -630,6 +631,7 @@ CDEV void queue_begin(MfmaQueue& q, float closestA, float closestB, int bestA, i
     q.result[lane] = hit_key(closestA, bestA);
     q.result[64 + lane] = hit_key(closestB, bestB);
     q.count = 0;
+    q.head = (((unsigned int)lane & 31u) << 23) | (((unsigned int)lane >> 5) << 30);
 }
 
 // After the last drain: every lane takes its two results back.
@@ -699,39 +701,56 @@ CDEV void drain_mfma(MfmaQueue& q, const SceneView& sc, const float4* lds_exact,
     tm.add(WaveTimers::kLists, t0);
 }
 
-// One column block against one sphere block: two matrix instructions leave key - threshold of 16
-// spheres in the lane's registers; a clear sign bit is a candidate.  The 16 signs are gathered
-// into a mask (one v_alignbit each; register v in bit 15 - v) and the lanes with candidates append
-// their entries to the wave's queue.
+// One column block against one sphere block: two matrix instructions leave threshold - key of 16
+// spheres in the lane's registers (the table holds the negated sphere operand); a set sign bit is a
+// candidate.  The 16 signs are gathered into a mask (one v_alignbit each; register v in bit 15 - v)
+// and the lanes with candidates append their entries to the wave's queue.
 template <int CB>
-CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk /* in the tile */, MfmaQueue& q)
+CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, unsigned int block_head, MfmaQueue& q)
 {
     f16x acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
-    unsigned int neg = 0u;
+    unsigned int cand = 0u;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) neg = push_sign(neg, acc[v]);
-    const unsigned int cand = ~neg & 0xFFFFu;
+    for (int v = 0; v < 16; ++v) cand = push_sign(cand, acc[v]);
     const unsigned long long hits = __ballot(cand != 0u);
     if (hits != 0ull) {
         CASTER_STAT(12);
         if (cand != 0u) {
-            const unsigned int lane = threadIdx.x & 63u;
-            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
-            // ray r = lane & 31, parity and slot of the column block, writer half
-            const unsigned int head = ((lane & 31u) << 23) | ((unsigned int)(CB & 1) << 28) | ((unsigned int)(CB >> 1) << 29) |
-                                      ((lane >> 5) << 30);
-            q.entries[(unsigned int)q.count + rank] = head | ((unsigned int)blk << 16) | cand;
+            // position: entries of this column block in lane order behind what the queue holds
+            const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((unsigned)hits, (unsigned int)q.count));
+            // block_head: the lane's part (ray r = lane & 31, writer half) and the block; the rest is
+            // the parity and slot of the column block
+            q.entries[pos] = cand | block_head | (((unsigned int)(CB & 1) << 28) | ((unsigned int)(CB >> 1) << 29));
         }
         q.count += __popcll(hits);
     }
 }
 
-// The sphere loop: all blocks of the table against the wave's four column blocks.  The queue is
-// worked off when the next block might not fit, at the end of a tile of blocks (an entry names a
-// block within its tile) and at the end.  The table holds one block more than the scene needs (read
-// ahead).
+// The sphere loop: all blocks of the table against the wave's four column blocks, two blocks per
+// turn so that the operand registers alternate (the next block is on its way while one is worked
+// on).  The queue is worked off when the next block might not fit, at the end of a tile of blocks
+// (an entry names a block within its tile) and at the end.  The table holds one block more than
+// the scene needs (read ahead).
+template <bool EXACT_LDS>
+CDEV void mfma_block(const uint4 a0, const uint4 a1, int blk, int& base, const SceneView& sc, const float4* lds_exact,
+                     const MfmaRays& mr, MfmaQueue& q, const Slot& sa, const Slot& sb, WaveTimers& tm)
+{
+    const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
+    const int in_tile = blk & (kMfmaTileBlocks - 1);
+    if (q.count > kMfmaQueueCap - 256 || (in_tile == 0 && blk != 0)) {
+        drain_mfma<EXACT_LDS>(q, sc, lds_exact, base, sa, sb, tm);
+        base = (blk - in_tile) * 32;
+    }
+    const unsigned int block_head = q.head | ((unsigned int)in_tile << 16);
+    mfma_column<0>(A0, A1, mr.b00, mr.b01, block_head, q);
+    mfma_column<1>(A0, A1, mr.b10, mr.b11, block_head, q);
+    mfma_column<2>(A0, A1, mr.b20, mr.b21, block_head, q);
+    mfma_column<3>(A0, A1, mr.b30, mr.b31, block_head, q);
+}
+
 template <bool EXACT_LDS>
 CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks, const MfmaRays& mr, MfmaQueue& q,
                      const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
@@ -741,21 +760,15 @@ CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks,
     const uint4* tab = sc.mfma_tab + (threadIdx.x & 63);
     uint4 a0 = tab[0], a1 = tab[64];
     int base = 0;
+    int blk = 0;
 #pragma unroll 1
-    for (int blk = 0; blk < n_blocks; ++blk) {
-        const uint4 n0 = tab[(blk + 1) * 128], n1 = tab[(blk + 1) * 128 + 64];
-        const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
-        const int in_tile = blk & (kMfmaTileBlocks - 1);
-        if (q.count > kMfmaQueueCap - 256 || (in_tile == 0 && blk != 0)) {
-            drain_mfma<EXACT_LDS>(q, sc, lds_exact, base, sa, sb, tm);
-            base = (blk - in_tile) * 32;
-        }
-        mfma_column<0>(A0, A1, mr.b00, mr.b01, in_tile, q);
-        mfma_column<1>(A0, A1, mr.b10, mr.b11, in_tile, q);
-        mfma_column<2>(A0, A1, mr.b20, mr.b21, in_tile, q);
-        mfma_column<3>(A0, A1, mr.b30, mr.b31, in_tile, q);
-        a0 = n0; a1 = n1;
+    for (; blk + 1 < n_blocks; blk += 2) {
+        const uint4 b0 = tab[(blk + 1) * 128], b1 = tab[(blk + 1) * 128 + 64];
+        mfma_block<EXACT_LDS>(a0, a1, blk, base, sc, lds_exact, mr, q, sa, sb, tm);
+        a0 = tab[(blk + 2) * 128]; a1 = tab[(blk + 2) * 128 + 64];
+        mfma_block<EXACT_LDS>(b0, b1, blk + 1, base, sc, lds_exact, mr, q, sa, sb, tm);
     }
+    if (blk < n_blocks) mfma_block<EXACT_LDS>(a0, a1, blk, base, sc, lds_exact, mr, q, sa, sb, tm);
     drain_mfma<EXACT_LDS>(q, sc, lds_exact, base, sa, sb, tm);
     queue_end(q, closestA, closestB, bestA, bestB);
 }
