@@ -718,12 +718,13 @@ CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, unsign
     if (hits != 0ull) {
         CASTER_STAT(12);
         if (cand != 0u) {
-            // position: entries of this column block in lane order behind what the queue holds
-            const unsigned int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((unsigned)hits, (unsigned int)q.count));
+            // position: entries of this column block in lane order behind what the queue holds (a
+            // scalar address plus the lane's rank)
+            const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
+            unsigned int* tail = q.entries + q.count;
             // block_head: the lane's part (ray r = lane & 31, writer half) and the block; the rest is
             // the parity and slot of the column block
-            q.entries[pos] = cand | block_head | (((unsigned int)(CB & 1) << 28) | ((unsigned int)(CB >> 1) << 29));
+            tail[rank] = cand | block_head | (((unsigned int)(CB & 1) << 28) | ((unsigned int)(CB >> 1) << 29));
         }
         q.count += __popcll(hits);
     }
@@ -947,7 +948,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     stage_noise(sc, a.scene, reinterpret_cast<unsigned char*>(s_noise_vec));   // read 98 times per shaded noise texel
     const Cam cam = cam_of(a.cam);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the same in all lanes: per-wave LDS addresses stay scalar
     const int tiles_x = (a.width + kTileW - 1) / kTileW;
     const int tiles_y = (a.height + kTileH - 1) / kTileH;
     const int n_tiles = tiles_x * tiles_y;
