@@ -538,7 +538,7 @@ CDEV RayHalves ray_halves(const Slot& s, const float3 ref, float scale)
     const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f[6]), __builtin_fabsf(f[7])), __builtin_fabsf(f[8]));
     // A slot without a path, or a non-finite ray (non_finite_rule decides for it): never a
     // candidate.  A ray so far out that its features leave half-precision range: a candidate for
-    // every sphere (the list code then runs the exact test on all of them).
+    // every sphere (the queue code then runs the exact test on all of them).
     const bool never = !s.alive || !r.finite;
     const float tneg = -thr * (1.0f / kThrScale);           // three halves of it go against kThrScale in the sphere operand
     const bool all = !never && !(big < 60000.0f && __builtin_fabsf(tneg) < 60000.0f);
