@@ -186,17 +186,16 @@ CDEV void flush_unit(const Unit& un, acc_t* acc_set, const RenderArgs& a, int la
 }
 
 // floor(x * 2^32) for a radiance value: a product of colours and an emission, finite and >= 0 for
-// any sane scene (clamped to [0, 1e9], NaN -> 0).  Integer arithmetic on the float's fields: the
-// result equals (u64)((double)x * 2^32) bit for bit without the slow double-to-u64 conversion.
+// any sane scene (clamped to [0, 1e9], NaN -> 0).  The integer part and the fraction are converted
+// separately: x - trunc(x) is exact in binary32, and so is its product with 2^32, so the result
+// equals (u64)((double)x * 2^32) bit for bit without a double-to-u64 conversion or 64-bit shifts.
 CDEV acc_t to_fixed(float x)
 {
-    const unsigned int b = __float_as_uint(fminf(fmaxf(x, 0.0f), 1.0e9f));
-    const int e = (int)(b >> 23);                               // biased exponent, <= 156
-    const unsigned long long m = e ? (unsigned long long)((b & 0x7FFFFFu) | 0x800000u) : 0ull;   // denormals are < 2^-32
-    const int sh = e - 118;                                     // x * 2^32 = m * 2^(e - 150 + 32)
-    const int left = sh > 0 ? sh : 0;
-    const int right = sh < 0 ? (-sh < 63 ? -sh : 63) : 0;
-    return (m << left) >> right;
+    const float c = fminf(fmaxf(x, 0.0f), 1.0e9f);
+    const unsigned int hi = (unsigned int)c;                    // truncates; c < 2^32
+    const float frac = c - (float)hi;                           // exact (0 when c >= 2^24)
+    const unsigned int lo = (unsigned int)(frac * 4294967296.0f);
+    return ((acc_t)hi << 32) | (acc_t)lo;
 }
 
 // ---- sphere loop ---------------------------------------------------------
