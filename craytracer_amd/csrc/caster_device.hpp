@@ -148,7 +148,7 @@ CDEV V3 to_unit(V3 v) { return v / sqrtf(dot(v, v)); }                          
 // Replaces rand() (src/common.c:10-13).  One xoshiro128+ stream per path: the
 // four state words are a chain of 32-bit avalanche hashes of (seed, pixel,
 // sample); a draw is the top 24 bits of the output, random_f32 = n / 2^24.
-// A draw costs nine full-rate integer ops and no multiply, which matters
+// A draw costs eight full-rate integer ops and no multiply, which matters
 // because the rejection samplers make the wave pay for its slowest lane.
 struct Rng { uint32_t s0, s1, s2, s3; uint32_t draws; };
 
@@ -172,16 +172,20 @@ CDEV void rng_seed(Rng& g, uint32_t seed, uint32_t pixel, uint32_t sample)
     g.draws = 0;
 }
 
+CDEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
+// One xoshiro128+ step: s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= s1 << 9; s3 = rotl(s3, 11),
+// written with three-input xors (one instruction each) so that a draw is eight integer operations.
 CDEV uint32_t rng_next24(Rng& g)
 {
     const uint32_t result = g.s0 + g.s3;
     const uint32_t t = g.s1 << 9;
-    g.s2 ^= g.s0;
-    g.s3 ^= g.s1;
-    g.s1 ^= g.s2;
-    g.s0 ^= g.s3;
-    g.s2 ^= t;
-    g.s3 = (g.s3 << 11) | (g.s3 >> 21);
+    const uint32_t n1 = xor3(g.s1, g.s2, g.s0);
+    const uint32_t n0 = xor3(g.s0, g.s3, g.s1);
+    const uint32_t n2 = xor3(g.s2, g.s0, t);
+    const uint32_t x3 = g.s3 ^ g.s1;
+    g.s0 = n0; g.s1 = n1; g.s2 = n2;
+    g.s3 = (x3 << 11) | (x3 >> 21);
     return result >> 8;
 }
 
