@@ -286,7 +286,7 @@ def _grazing_rays(rng, fs, n):
     return np.concatenate([o, d], axis=1).astype(np.float32)
 
 
-@pytest.mark.parametrize("scene_name", ["rtiow", "stress_2600", "scene_0", "offset_scene", "mixed_scales"])
+@pytest.mark.parametrize("scene_name", ["rtiow", "stress_2600", "stress_4500", "scene_0", "offset_scene", "mixed_scales"])
 def test_production_sphere_loop_parity(gpu, orc, ca, scene_name):
     """hit_list_hit_all through the render kernel's own loop (LDS tiles, candidate filter, packed slots):
     every hit/miss decision, object and t must equal the reference arithmetic, in particular where the
@@ -296,6 +296,8 @@ def test_production_sphere_loop_parity(gpu, orc, ca, scene_name):
         fs = ca.scene_rtiow(1)
     elif scene_name == "stress_2600":
         fs = ca.scene_stress(2600, 2)                      # three LDS tiles
+    elif scene_name == "stress_4500":
+        fs = ca.scene_stress(4500, 2)                      # more than 128 blocks of 32 spheres in the matrix loop
     elif scene_name == "scene_0":
         fs = ca.scene_0()
     elif scene_name == "mixed_scales":

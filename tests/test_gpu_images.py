@@ -99,7 +99,7 @@ def test_fast_mode_is_scheduling_independent(gpu, ca):
     gpu.set_chunk(0)
 
 
-@pytest.mark.parametrize("name", ["rtiow", "perlin", "scene_0_textured", "stress_500", "stress_1500", "offset"])
+@pytest.mark.parametrize("name", ["rtiow", "perlin", "scene_0_textured", "stress_500", "stress_1500", "stress_4500", "offset"])
 def test_matrix_and_vector_loops_give_identical_frames(gpu, ca, name):
     """The conservative sphere filter runs on the matrix cores (half-precision pieces, a wider
     margin) where the scene qualifies and on the vector unit otherwise; either way the candidates go
@@ -116,6 +116,8 @@ def test_matrix_and_vector_loops_give_identical_frames(gpu, ca, name):
         fs = ca.scene_stress(500, 2)
     elif name == "stress_1500":
         fs = ca.scene_stress(1500, 2)                   # more than one tile of 512: exact operands from device memory
+    elif name == "stress_4500":
+        fs = ca.scene_stress(4500, 2)                   # more than 128 blocks of 32: the queue entries' block numbers start over
     else:
         fs = ca.scene_rtiow(5)                          # far from the origin: the filter's reference point and scale at work
         objs = fs.objects.copy()
@@ -124,6 +126,8 @@ def test_matrix_and_vector_loops_give_identical_frames(gpu, ca, name):
         fs = ca.FlatScene(objs, fs.materials, [])
     gpu.upload_scene(fs)
     w, h, spp, depth, seed = 480, 270, 12, 50, 17
+    if name == "stress_4500":
+        w, h, spp = 240, 135, 6
     cam = ca.default_camera(w / h)
     if name == "offset":
         cam = ca.calculate_cam_info((3013, 2, -1497), (3000, 0, -1500), (0, 1, 0), 20.0, np.float32(w / h), 0.1, 10.0)
