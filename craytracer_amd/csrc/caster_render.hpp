@@ -416,6 +416,7 @@ CDEV Group load_group(filter_ptr src, int k)
 }
 
 // Shifts the sign bit of x into m from the right.
+CDEV unsigned int or3(unsigned int a, unsigned int b, unsigned int c) { return a | b | c; }
 CDEV unsigned int push_sign(unsigned int m, float x) { return __builtin_amdgcn_alignbit(m, __float_as_uint(x), 31u); }
 
 // Evaluates the candidate keys of a group and looks at them together: a sphere is a candidate
@@ -710,13 +711,19 @@ CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, unsign
     f16x acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
-    unsigned int cand = 0u;
+    // Three column blocks in four have no candidate at all: the sign of the OR of the 16 results
+    // tells (8 three-input ORs), and the masks are gathered only where some lane has one.
+    unsigned int any = __float_as_uint(acc[0]);
 #pragma unroll
-    for (int v = 0; v < 16; ++v) cand = push_sign(cand, acc[v]);
-    const unsigned long long hits = __ballot(cand != 0u);
+    for (int v = 1; v < 15; v += 2) any = or3(any, __float_as_uint(acc[v]), __float_as_uint(acc[v + 1]));
+    any |= __float_as_uint(acc[15]);
+    const unsigned long long hits = __ballot((int)any < 0);
     if (hits != 0ull) {
         CASTER_STAT(12);
-        if (cand != 0u) {
+        unsigned int cand = 0u;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) cand = push_sign(cand, acc[v]);
+        if ((int)any < 0) {         // the lanes of `hits`: those with a bit in cand
             // position: entries of this column block in lane order behind what the queue holds (a
             // scalar address plus the lane's rank)
             const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, 0u));
