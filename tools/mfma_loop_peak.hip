@@ -3,7 +3,9 @@
 // (variant 0) or four independent v_mfma_f32_16x16x32_f16 (variant 1), then the 16 sign masks and
 // the test for candidates (never taken); variant 2 issues the matrix instructions of variant 0 alone
 // (one register of the result is looked at), variant 3 the sign masks and the test alone (on the
-// operand registers).  Prints the time per column block and SIMD.
+// operand registers), variant 4 the matrix instructions and the OR of the 16 results that tells
+// whether the column block has a candidate (what the render kernel does where it has none).  Prints
+// the time per column block and SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -24,6 +26,15 @@ __device__ __forceinline__ unsigned column(const h8 a0, const h8 a1, const h8 b0
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < 16; ++v) cand = push_sign(cand, acc[v]);
+    } else if (V == 4) {
+        f16x acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+        unsigned any = __float_as_uint(acc[0]);
+#pragma unroll
+        for (int v = 1; v < 15; v += 2) any = any | __float_as_uint(acc[v]) | __float_as_uint(acc[v + 1]);
+        any |= __float_as_uint(acc[15]);
+        cand = any >> 31;
     } else if (V == 2) {
         f16x acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
@@ -91,14 +102,16 @@ int main()
     const int blocks = p.multiProcessorCount * 4;
     (void)hipMalloc(&d_out, blocks * 256 * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    const char* names[4] = {"2 x 32x32x16, dependent", "4 x 16x16x32, independent", "matrix instructions only", "sign masks only"};
-    for (int v = 0; v < 4; ++v) {
+    const char* names[5] = {"2 x 32x32x16, dependent", "4 x 16x16x32, independent", "matrix instructions only", "sign masks only",
+                            "2 x 32x32x16 and the OR of the results"};
+    for (int v = 0; v < 5; ++v) {
         for (int rep = 0; rep < 3; ++rep) {
             (void)hipEventRecord(e0);
             if (v == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, d_tab, n_blocks, trips, d_rays, d_out);
             else if (v == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d_tab, n_blocks, trips, d_rays, d_out);
             else if (v == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, d_tab, n_blocks, trips, d_rays, d_out);
-            else hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, d_tab, n_blocks, trips, d_rays, d_out);
+            else if (v == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, d_tab, n_blocks, trips, d_rays, d_out);
+            else hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, d_tab, n_blocks, trips, d_rays, d_out);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
             // per SIMD: 4 waves x trips x n_blocks x 4 column blocks
