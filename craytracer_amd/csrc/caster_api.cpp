@@ -211,8 +211,7 @@ static void split_half_host(double x, _Float16& hi, _Float16& lo)
     lo = (_Float16)(float)(x - (double)(float)hi);
 }
 
-static int build_matrix_tables(caster_hip_ctx* ctx, const std::vector<float4>& sph, const std::vector<float4>& sph_filter,
-                               const std::vector<float>& sph_scale)
+static int build_matrix_tables(caster_hip_ctx* ctx, const std::vector<float4>& sph, const std::vector<float4>& sph_filter)
 {
     caster::SceneDev& s = ctx->scene;
     s.mfma_tab[0] = s.mfma_tab[1] = nullptr;
@@ -266,7 +265,6 @@ static int build_matrix_tables(caster_hip_ctx* ctx, const std::vector<float4>& s
                 slot[27] = (_Float16)(-60000.0f);   // never a candidate: pad rows and the spheres that are tested directly
             }
             slot[29] = slot[30] = slot[31] = (_Float16)1024.0f;   // against the three halves of -threshold / 1024
-            (void)sph_scale;
             // The table holds the NEGATED operand: the product is then threshold - key, and a set
             // sign bit marks a candidate (the kernel gathers sign bits; no complement needed).
             const size_t blk = k / 32, r = k % 32;
@@ -382,8 +380,6 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
     caster::SceneDev& s = ctx->scene;
     int rc;
     if ((rc = upload_array(ctx, sph, &s.sph))) return rc;
-    if ((rc = upload_array(ctx, sph_filter, &s.sph_filter))) return rc;
-    if ((rc = upload_array(ctx, sph_scale, &s.sph_scale))) return rc;
     for (int mode = 0; mode < 2; ++mode) {
         const float margin = mode ? caster::kFilterMarginStrict : caster::kFilterMarginFast;
         std::vector<float4> img(sph.size() + 16, make_float4(0.0f, 0.0f, -1.0e30f, 0.0f));
@@ -394,7 +390,7 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
         if ((rc = upload_array(ctx, img, &s.filter_img[mode]))) return rc;
     }
     s.ref[0] = (float)ref[0]; s.ref[1] = (float)ref[1]; s.ref[2] = (float)ref[2];
-    if ((rc = build_matrix_tables(ctx, sph, sph_filter, sph_scale))) return rc;
+    if ((rc = build_matrix_tables(ctx, sph, sph_filter))) return rc;
     if ((rc = upload_array(ctx, sph_meta, &s.sph_meta))) return rc;
     if ((rc = upload_array(ctx, rect_a, &s.rect_a))) return rc;
     if ((rc = upload_array(ctx, rect_b, &s.rect_b))) return rc;

@@ -112,8 +112,6 @@ struct Cam { V3 o, llc, h, v, u0, v0; float lr; };
 struct SceneView {
     const float4* sph;      // cx, cy, cz, r
     const int2*   sph_meta; // list position, material
-    const float4* sph_filter;
-    const float*  sph_scale;
     const float4* filter_img;
     const uint4* mfma_tab;
     const float4* rect_a;   // cx, cy, cz, du

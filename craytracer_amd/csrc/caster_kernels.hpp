@@ -19,7 +19,7 @@ static_assert(sizeof(CamRec) == sizeof(Cam), "camera record layout");
 CDEV SceneView view_of(const SceneDev& s)
 {
     SceneView v;
-    v.sph = s.sph; v.sph_meta = s.sph_meta; v.sph_filter = s.sph_filter; v.sph_scale = s.sph_scale;
+    v.sph = s.sph; v.sph_meta = s.sph_meta;
     v.rect_a = s.rect_a; v.rect_b = s.rect_b; v.rect_meta = s.rect_meta;
     v.mats = reinterpret_cast<const Mat*>(s.mats);
     v.imgs = reinterpret_cast<const Img*>(s.imgs);

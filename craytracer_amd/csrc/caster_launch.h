@@ -31,8 +31,6 @@ constexpr int kMfmaMinSpheres = 33;   // below this the vector loop is as fast o
 struct SceneDev {
     const float4* sph;       // cx, cy, cz, r            (list order among spheres)
     const int2*   sph_meta;  // list position, material
-    const float4* sph_filter;// candidate filter: cx-Px, cy-Py, cz-Pz, C - r*r   (C = |c-P|^2; -inf = always a candidate, +inf = never: listed in `always`)
-    const float*  sph_scale; // C + r*r, the scale of the filter's rounding error
     const float4* filter_img[2]; // the filter entries as the loop reads them (fast, strict), padded with 16 never-candidates
     const float4* rect_a;    // cx, cy, cz, du
     const float4* rect_b;    // dv, 0, 0, 0
