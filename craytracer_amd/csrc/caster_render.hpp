@@ -1005,26 +1005,27 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     bool queue_empty = false;
 
     for (;;) {
-        const unsigned long long t_sched = tm.now();
-        if (cur.chunk >= 0 && cur.next >= cur.total) {
-            flush_unit(cur, wave_acc, a, lane);
-            cur.chunk = -1;
-            cur.tg.tw = cur.tg.th = 0;      // no current tile
-        }
-        if (cur.chunk < 0 && !queue_empty) {
-            cur = fetch_unit(a, tiles_x, n_tiles, lane);
-            queue_empty = cur.chunk < 0;
-            tm.fetched(!queue_empty, cur.chunk, cur.tg.x0 / kTileW, cur.tg.y0 / kTileH);
-        }
-        tm.add(WaveTimers::kSchedule, t_sched);
-
         // One copy of the per-slot code serves both slots (the slots trade places
-        // after each turn), so a path computes the same values in either slot.
+        // after each turn), so a path computes the same values in either slot.  The unit is
+        // changed between a slot's bounce and its refill: when the pool ran dry in the first slot's
+        // refill, the second slot already draws on the next unit in the same trip.
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {
             const unsigned long long t_bounce = tm.now();
             bounce(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
             tm.add(WaveTimers::kBounce, t_bounce);
+            const unsigned long long t_sched = tm.now();
+            if (cur.chunk >= 0 && cur.next >= cur.total) {
+                flush_unit(cur, wave_acc, a, lane);
+                cur.chunk = -1;
+                cur.tg.tw = cur.tg.th = 0;      // no current tile
+            }
+            if (cur.chunk < 0 && !queue_empty) {
+                cur = fetch_unit(a, tiles_x, n_tiles, lane);
+                queue_empty = cur.chunk < 0;
+                tm.fetched(!queue_empty, cur.chunk, cur.tg.x0 / kTileW, cur.tg.y0 / kTileH);
+            }
+            tm.add(WaveTimers::kSchedule, t_sched);
             const unsigned long long t_refill = tm.now();
             refill(sa, cur, a, cam);
             tm.add(WaveTimers::kRefill, t_refill);
