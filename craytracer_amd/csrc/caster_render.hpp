@@ -132,8 +132,43 @@ CDEV Unit fetch_unit(const RenderArgs& a, int tiles_x, int n_tiles, int lane)
     return un;
 }
 
+// The divisions (i + jitter) / (width - 1) and (j + jitter) / (height - 1) of src/dispatcher.c:21-22
+// share their denominators over the whole frame.  The compiler's correctly rounded division is a
+// reciprocal refined once and a chain of four fused corrections, wrapped in a scaling of operands in
+// extreme ranges; for a numerator in [0, 65536) and an integer denominator in [1, 65535] nothing is
+// scaled, so the same chain on a reciprocal kept from the kernel's start gives the same bits
+// (tools/div_check.hip compares 7e10 quotients).  A frame one pixel wide or high divides by zero as
+// the reference does: the plain division then.
+struct PixelScale {
+    float dw, rw, dh, rh;   // denominators and their refined reciprocals (wave-uniform)
+    bool chain;
+};
+
+CDEV PixelScale pixel_scale(int width, int height)
+{
+    PixelScale p;
+    p.dw = (float)(width - 1);
+    p.dh = (float)(height - 1);
+    p.chain = width > 1 && height > 1;
+    const float w0 = __builtin_amdgcn_rcpf(p.dw), h0 = __builtin_amdgcn_rcpf(p.dh);
+    const float rw = __builtin_fmaf(__builtin_fmaf(-p.dw, w0, 1.0f), w0, w0);
+    const float rh = __builtin_fmaf(__builtin_fmaf(-p.dh, h0, 1.0f), h0, h0);
+    p.rw = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rw)));
+    p.rh = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(rh)));
+    return p;
+}
+
+CDEV float divide_by(float n, float d, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+
 // Camera ray for pool entry m of the unit: src/dispatcher.c:21-24.
-CDEV void start_pool_path(Slot& s, int m, const Unit& un, const RenderArgs& a, const Cam& cam)
+CDEV void start_pool_path(Slot& s, int m, const Unit& un, const RenderArgs& a, const Cam& cam, const PixelScale& ps)
 {
     const int nvalid = un.tg.tw * un.tg.th;
     int smp, qx, qy;
@@ -147,8 +182,16 @@ CDEV void start_pool_path(Slot& s, int m, const Unit& un, const RenderArgs& a, c
     }
     const int i = un.tg.x0 + qx, j = un.tg.y0 + qy;
     rng_seed(s.g, a.seed, (uint32_t)(j * a.width + i), (uint32_t)(un.s0 + smp));
-    const float u = ((float)i + random_f32(s.g)) / (float)(a.width - 1);
-    const float v = ((float)j + random_f32(s.g)) / (float)(a.height - 1);
+    const float un_ = (float)i + random_f32(s.g);
+    const float vn_ = (float)j + random_f32(s.g);
+    float u, v;
+    if (ps.chain) {
+        u = divide_by(un_, ps.dw, ps.rw);
+        v = divide_by(vn_, ps.dh, ps.rh);
+    } else {
+        u = un_ / ps.dw;
+        v = vn_ / ps.dh;
+    }
     const Ray r = ray_from_cam(cam, s.g, u, v);
     set_ray(s, r);
     s.thr = mk(1.0f, 1.0f, 1.0f);
@@ -158,14 +201,14 @@ CDEV void start_pool_path(Slot& s, int m, const Unit& un, const RenderArgs& a, c
 }
 
 // Slots without a path take the next entries of the unit's pool, in lane order.
-CDEV void refill(Slot& s, Unit& un, const RenderArgs& a, const Cam& cam)
+CDEV void refill(Slot& s, Unit& un, const RenderArgs& a, const Cam& cam, const PixelScale& ps)
 {
     if (un.chunk < 0 || un.next >= un.total) return;             // wave-uniform
     const unsigned long long want = __ballot(!s.alive);
     if (want == 0ull) return;
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
     const int m = un.next + rank;
-    if (!s.alive && m < un.total) { CASTER_STAT(11); start_pool_path(s, m, un, a, cam); }
+    if (!s.alive && m < un.total) { CASTER_STAT(11); start_pool_path(s, m, un, a, cam, ps); }
     un.next += __popcll(want);
 }
 
@@ -953,6 +996,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     SceneView sc = view_of(a.scene);
     stage_noise(sc, a.scene, reinterpret_cast<unsigned char*>(s_noise_vec));   // read 98 times per shaded noise texel
     const Cam cam = cam_of(a.cam);
+    const PixelScale ps = pixel_scale(a.width, a.height);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // the same in all lanes: per-wave LDS addresses stay scalar
     const int tiles_x = (a.width + kTileW - 1) / kTileW;
@@ -1027,7 +1071,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
             }
             tm.add(WaveTimers::kSchedule, t_sched);
             const unsigned long long t_refill = tm.now();
-            refill(sa, cur, a, cam);
+            refill(sa, cur, a, cam, ps);
             tm.add(WaveTimers::kRefill, t_refill);
             swap_slots(sa, sb);
             float tf = closestA; closestA = closestB; closestB = tf;
