@@ -137,7 +137,34 @@ CDEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }   
 CDEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }   // common.c:55-63
 CDEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }   // common.c:65-72
 CDEV V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }      // common.c:33
-CDEV V3 operator/(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }      // common.c:34
+// common.c:34.  Three correctly rounded quotients over one denominator.  The compiler's division is a
+// reciprocal refined once and a chain of four fused corrections, wrapped in a scaling of operands in
+// extreme ranges and a fix-up of zeros, infinities and NaNs; when all four magnitudes lie in
+// [2^-40, 2^40] neither does anything, and the same chain on one shared reciprocal gives the same
+// bits (tools/div_check.hip compares 1e11 quotients).  Anything else takes the plain division.
+CDEV float div_chain(float n, float d, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+
+CDEV V3 operator/(V3 a, float s)
+{
+#if CASTER_STRICT
+    const float as = __builtin_fabsf(s), ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z);
+    const float lo = __builtin_fminf(__builtin_fminf(ax, ay), __builtin_fminf(az, as));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), __builtin_fmaxf(az, as));
+    if (lo >= 0x1p-40f && hi <= 0x1p40f) {
+        const float r0 = __builtin_amdgcn_rcpf(s);
+        const float r = __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
+        return mk(div_chain(a.x, s, r), div_chain(a.y, s, r), div_chain(a.z, s, r));
+    }
+#endif
+    return mk(a.x / s, a.y / s, a.z / s);
+}
 CDEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }                              // common.c:36-43
 CDEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y + a.z * b.z); }      // common.c:84-87
 CDEV V3 to_unit(V3 v) { return v / sqrtf(dot(v, v)); }                          // common.c:89-97
