@@ -34,4 +34,12 @@ from .binding import (  # noqa: F401
     scene_stress,
     make_test_texture,
     bmp_encode,
+    reduce,
+    LOOP_NAMES,
+    MATH_REFLECTANCE,
+    MATH_REFRACT,
+    MATH_REFLECT,
+    MATH_UV_SPHERE,
+    MATH_NEAR_ZERO,
+    MATH_TO_UNIT,
 )

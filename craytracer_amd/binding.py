@@ -36,6 +36,15 @@ class CasterHipError(RuntimeError):
     pass
 
 
+class _RenderInfo(C.Structure):      # caster_render_info
+    _fields_ = [("loop_kind", C.c_int32), ("mfma_blocks", C.c_int32), ("n_spheres", C.c_int32), ("kernel_ms", C.c_float),
+                ("rays", C.c_uint64), ("wave_trips", C.c_uint64)]
+
+
+MATH_REFLECTANCE, MATH_REFRACT, MATH_REFLECT, MATH_UV_SPHERE, MATH_NEAR_ZERO, MATH_TO_UNIT = range(6)
+LOOP_NAMES = {0: "vector", 1: "vector_tiled", 2: "matrix", 3: "matrix_large"}
+
+
 class _Image(C.Structure):
     _fields_ = [("data", C.c_void_p), ("w", C.c_uint32), ("h", C.c_uint32), ("bpp", C.c_uint32)]
 
@@ -361,6 +370,13 @@ class CasterHip:
             "caster_hip_render",
         )
 
+    def render_info(self) -> dict:
+        """caster_hip_render_info of the last render: loop kind, blocks, wave trips, rays, kernel ms."""
+        info = _RenderInfo()
+        _check(self._lib.caster_hip_render_info(self._ctx, C.byref(info)), "caster_hip_render_info")
+        return dict(loop_kind=info.loop_kind, loop=LOOP_NAMES.get(info.loop_kind, "none"), mfma_blocks=info.mfma_blocks,
+                    n_spheres=info.n_spheres, kernel_ms=info.kernel_ms, rays=info.rays, wave_trips=info.wave_trips)
+
     def render_stats(self):
         rays, ms = C.c_uint64(), C.c_float()
         _check(self._lib.caster_hip_render_stats(self._ctx, C.byref(rays), C.byref(ms)), "caster_hip_render_stats")
@@ -475,8 +491,36 @@ class CasterHip:
         )
         return rgb
 
+    def test_math(self, fn, in8, strict=True):
+        in8 = _f32(in8, (-1, 8))
+        out = np.zeros((len(in8), 3), np.float32)
+        _check(self._lib.caster_hip_test_math(self._ctx, C.c_uint32(STRICT if strict else 0), C.c_int(fn), C.c_int(len(in8)), _ptr(in8), _ptr(out)),
+               "caster_hip_test_math")
+        return out
+
+    def filter_audit(self, ray6, strict=True, vector_loop=False):
+        """caster_hip_filter_audit: per ray, spheres the exact test accepts, those of them the filter rejected, smallest slack."""
+        ray6 = _f32(ray6, (-1, 6))
+        n = len(ray6)
+        accepted, missed, slack = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.float32)
+        _check(
+            self._lib.caster_hip_filter_audit(self._ctx, C.c_uint32((STRICT if strict else 0) | (VECTOR_LOOP if vector_loop else 0)), C.c_int(n),
+                                              _ptr(ray6), _ptr(accepted), _ptr(missed), _ptr(slack)),
+            "caster_hip_filter_audit",
+        )
+        return dict(accepted=accepted, missed=missed, slack=slack)
+
     def test_rng(self, seed, pixel, sample, n):
         out = np.zeros(n, np.uint32)
         _check(self._lib.caster_hip_test_rng(self._ctx, C.c_uint32(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_int(n), _ptr(out)),
                "caster_hip_test_rng")
         return out
+
+
+def reduce(contexts: Sequence["CasterHip"], accum_ptrs: Sequence[int], n_floats: int):
+    """caster_hip_reduce: accum_ptrs[0] receives the sum of all the buffers (one context per GPU) through RCCL."""
+    lib = load_caster_lib()
+    n = len(contexts)
+    ctxs = (C.c_void_p * n)(*[c._ctx.value for c in contexts])
+    bufs = (C.c_void_p * n)(*accum_ptrs)
+    _check(lib.caster_hip_reduce(ctxs, bufs, C.c_int(n), C.c_size_t(n_floats)), "caster_hip_reduce")

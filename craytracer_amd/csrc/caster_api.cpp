@@ -4,6 +4,9 @@
 #include "caster_launch.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is opened at run time (see Rccl)
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -11,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -34,6 +38,8 @@ int fail(int code, const char* fmt, ...)
             return fail(CASTER_HIP_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+constexpr int kCounterWords = 4;
+
 }  // namespace
 
 struct caster_hip_ctx {
@@ -49,11 +55,16 @@ struct caster_hip_ctx {
     // scratch
     unsigned long long* fixed = nullptr;      // per-pixel fixed-point sums of the call in flight
     size_t fixed_bytes = 0;
-    unsigned long long* rays_dev = nullptr;   // [0] rays, [1] low word: work-unit queue head
+    unsigned long long* counters = nullptr;   // kCounterWords words: [0] rays, [1] low word: work-unit queue head, [2] wave trips
     int resident_blocks = 1024;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool render_pending = false;
     int chunk = 0;  // samples per work unit; 0 = automatic
+    // what the last render launched
+    const unsigned long long* last_counters = nullptr;
+    int last_kind = -1;
+    int last_blocks = 0;
+    int last_spheres = 0;
 };
 
 namespace {
@@ -162,8 +173,8 @@ int caster_hip_create(int device, caster_hip_ctx** out)
     }
     const char* env_chunk = getenv("CASTER_HIP_CHUNK");
     if (env_chunk) ctx->chunk = atoi(env_chunk);
-    if (hipMalloc(reinterpret_cast<void**>(&ctx->rays_dev), 2 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(ctx->rays_dev, 0, 2 * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->counters), kCounterWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->counters, 0, kCounterWords * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         caster_hip_destroy(ctx);
         return fail(CASTER_HIP_ERR_DEVICE, "context allocation on device %d failed", device);
@@ -180,7 +191,7 @@ int caster_hip_destroy(caster_hip_ctx* ctx)
     free_scene(ctx);
     if (ctx->fixed) (void)hipFree(ctx->fixed);
     if (ctx->staging) (void)hipFree(ctx->staging);
-    if (ctx->rays_dev) (void)hipFree(ctx->rays_dev);
+    if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -518,39 +529,25 @@ static int plan_chunks(const caster_hip_ctx* ctx, int width, int height, int sam
     return n;
 }
 
-int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height,
-                      int sample_begin, int sample_count, int max_depth,
-                      uint32_t seed, uint32_t flags, float* accum_dev)
+// The body of both render entry points.  `fixed` (width * height * 4 words) and `counters`
+// (kCounterWords words) are the call's scratch: the context's own buffers.  Nothing here allocates.
+static int render_on(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height, int sample_begin,
+                     int sample_count, int max_depth, uint32_t seed, uint32_t flags, float* accum_dev,
+                     unsigned long long* fixed, unsigned long long* counters)
 {
-    if (!ctx || !cam || !accum_dev) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
-    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "render before caster_hip_upload_scene");
-    if (ctx->needs_noise && !ctx->scene.noise_vec)
-        return fail(CASTER_HIP_ERR_STATE, "the scene has a noise texture: call caster_hip_set_noise first");
-    if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
-        return fail(CASTER_HIP_ERR_ARG, "frame size %dx%d out of range", width, height);
-    if (sample_begin < 0 || sample_count < 0) return fail(CASTER_HIP_ERR_ARG, "negative sample range");
-    if ((flags & ~(uint32_t)(CASTER_HIP_STRICT | CASTER_HIP_VECTOR_LOOP)) != 0)
-        return fail(CASTER_HIP_ERR_ARG, "unknown flag bits 0x%x", flags);
-    DeviceGuard guard(ctx->device);
-    HIP_TRY(hipMemsetAsync(ctx->rays_dev, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(hipMemsetAsync(counters, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
     ctx->render_pending = true;
+    ctx->last_counters = counters;
+    ctx->last_kind = -1;
+    ctx->last_blocks = 0;
+    ctx->last_spheres = ctx->scene.n_sph;
     if (sample_count == 0) {
+        HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
         return CASTER_HIP_OK;
     }
-
     const size_t n_pixels = (size_t)width * height;
-    const size_t need = n_pixels * 4 * sizeof(unsigned long long);
-    if (need > ctx->fixed_bytes) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ctx->fixed) HIP_TRY(hipFree(ctx->fixed));
-        ctx->fixed = nullptr;
-        ctx->fixed_bytes = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->fixed), need));
-        ctx->fixed_bytes = need;
-    }
-    HIP_TRY(hipMemsetAsync(ctx->fixed, 0, need, ctx->stream));
+    HIP_TRY(hipMemsetAsync(fixed, 0, n_pixels * 4 * sizeof(unsigned long long), ctx->stream));
 
     caster::RenderArgs a;
     a.cam = cam_rec(cam);
@@ -561,17 +558,57 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     a.n_chunks = plan_chunks(ctx, width, height, sample_count, a.chunk_start);
     a.max_depth = max_depth;
     a.seed = seed;
-    a.fixed = ctx->fixed;
-    a.rays = ctx->rays_dev;
-    a.queue = reinterpret_cast<unsigned int*>(ctx->rays_dev + 1);
+    a.fixed = fixed;
+    a.rays = counters;
+    a.queue = reinterpret_cast<unsigned int*>(counters + 1);
+    a.trips = counters + 2;
     a.n_units = 0;
     a.lds_spheres = 0;
-    if (flags & CASTER_HIP_STRICT) HIP_TRY(caster::launch_render_strict(a, ctx->resident_blocks, ctx->stream));
+    const int strict = (flags & CASTER_HIP_STRICT) ? 1 : 0;
+    ctx->last_kind = caster::pick_loop_kind(a.scene, strict);
+    ctx->last_blocks = ctx->last_kind >= caster::kLoopMatrix ? a.scene.mfma_blocks : 0;
+    // the events bracket the path-tracing kernel alone
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    if (strict) HIP_TRY(caster::launch_render_strict(a, ctx->resident_blocks, ctx->stream));
     else HIP_TRY(caster::launch_render_fast(a, ctx->resident_blocks, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(caster::launch_fold(ctx->fixed, (int)n_pixels, sample_count, reinterpret_cast<float4*>(accum_dev),
-                                ctx->stream));
+    HIP_TRY(caster::launch_fold(fixed, (int)n_pixels, sample_count, reinterpret_cast<float4*>(accum_dev), ctx->stream));
     return CASTER_HIP_OK;
+}
+
+static int check_render_args(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height, int sample_begin,
+                             int sample_count, uint32_t flags, float* accum_dev)
+{
+    if (!ctx || !cam || !accum_dev) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "render before caster_hip_upload_scene");
+    if (ctx->needs_noise && !ctx->scene.noise_vec)
+        return fail(CASTER_HIP_ERR_STATE, "the scene has a noise texture: call caster_hip_set_noise first");
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
+        return fail(CASTER_HIP_ERR_ARG, "frame size %dx%d out of range", width, height);
+    if (sample_begin < 0 || sample_count < 0) return fail(CASTER_HIP_ERR_ARG, "negative sample range");
+    if ((flags & ~(uint32_t)(CASTER_HIP_STRICT | CASTER_HIP_VECTOR_LOOP)) != 0)
+        return fail(CASTER_HIP_ERR_ARG, "unknown flag bits 0x%x", flags);
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height,
+                      int sample_begin, int sample_count, int max_depth,
+                      uint32_t seed, uint32_t flags, float* accum_dev)
+{
+    int rc = check_render_args(ctx, cam, width, height, sample_begin, sample_count, flags, accum_dev);
+    if (rc) return rc;
+    DeviceGuard guard(ctx->device);
+    const size_t need = (size_t)width * height * 4 * sizeof(unsigned long long);
+    if (sample_count > 0 && need > ctx->fixed_bytes) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->fixed) HIP_TRY(hipFree(ctx->fixed));
+        ctx->fixed = nullptr;
+        ctx->fixed_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ctx->fixed), need));
+        ctx->fixed_bytes = need;
+    }
+    return render_on(ctx, cam, width, height, sample_begin, sample_count, max_depth, seed, flags, accum_dev,
+                     ctx->fixed, ctx->counters);
 }
 
 int caster_hip_add_from_device(caster_hip_ctx* ctx, float* dst_dev, int src_device, const float* src_dev, size_t n_floats)
@@ -604,10 +641,28 @@ int caster_hip_render_stats(caster_hip_ctx* ctx, uint64_t* rays, float* kernel_m
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (rays) {
         unsigned long long r = 0;
-        HIP_TRY(hipMemcpy(&r, ctx->rays_dev, sizeof r, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&r, ctx->last_counters, sizeof r, hipMemcpyDeviceToHost));
         *rays = (uint64_t)r;
     }
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_render_info(caster_hip_ctx* ctx, caster_render_info* out)
+{
+    if (!ctx || !out) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->render_pending) return fail(CASTER_HIP_ERR_STATE, "no render has been issued on this context");
+    DeviceGuard guard(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long c[kCounterWords] = {};
+    HIP_TRY(hipMemcpy(c, ctx->last_counters, sizeof c, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->loop_kind = ctx->last_kind;
+    out->mfma_blocks = ctx->last_blocks;
+    out->n_spheres = ctx->last_spheres;
+    out->rays = (uint64_t)c[0];
+    out->wave_trips = (uint64_t)c[2];
+    HIP_TRY(hipEventElapsedTime(&out->kernel_ms, ctx->ev0, ctx->ev1));
     return CASTER_HIP_OK;
 }
 
@@ -853,4 +908,146 @@ int caster_hip_test_rng(caster_hip_ctx* ctx, uint32_t seed, uint32_t pixel, uint
     return CASTER_HIP_OK;
 }
 
+int caster_hip_test_math(caster_hip_ctx* ctx, uint32_t flags, int fn, int n, const float* in8, float* out3)
+{
+    if (!ctx || !in8 || !out3) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    if (fn < 0 || fn > CASTER_MATH_TO_UNIT) return fail(CASTER_HIP_ERR_ARG, "unknown function %d", fn);
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf di, dout;
+    HIP_TRY(di.put(in8, sizeof(float) * 8 * n));
+    HIP_TRY(dout.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(PICK(flags, launch_test_math_)(fn, n, di.as<float>(), dout.as<float>(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(dout.get(out3, sizeof(float) * 3 * n));
+    return CASTER_HIP_OK;
+}
+
+int caster_hip_filter_audit(caster_hip_ctx* ctx, uint32_t flags, int n, const float* ray6,
+                            uint32_t* accepted, uint32_t* missed, float* slack)
+{
+    if (!ctx || !ray6 || !accepted || !missed || !slack) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx->has_scene) return fail(CASTER_HIP_ERR_STATE, "no scene uploaded");
+    if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
+    if ((flags & ~(uint32_t)(CASTER_HIP_STRICT | CASTER_HIP_VECTOR_LOOP)) != 0)
+        return fail(CASTER_HIP_ERR_ARG, "unknown flag bits 0x%x", flags);
+    if (n == 0) return CASTER_HIP_OK;
+    DeviceGuard guard(ctx->device);
+    DevBuf dr, da, dm, ds;
+    HIP_TRY(dr.put(ray6, sizeof(float) * 6 * n));
+    HIP_TRY(da.alloc(sizeof(uint32_t) * n));
+    HIP_TRY(dm.alloc(sizeof(uint32_t) * n));
+    HIP_TRY(ds.alloc(sizeof(float) * n));
+    caster::SceneDev scene = ctx->scene;
+    const int strict = (flags & CASTER_HIP_STRICT) ? 1 : 0;
+    // the same choice of loop as a render call makes
+    if ((flags & CASTER_HIP_VECTOR_LOOP) || caster::pick_loop_kind(scene, strict) < caster::kLoopMatrix) scene.mfma_blocks = 0;
+    HIP_TRY(PICK(flags, launch_filter_audit_)(scene, n, dr.as<float>(), da.as<uint32_t>(), dm.as<uint32_t>(),
+                                              ds.as<float>(), ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(da.get(accepted, sizeof(uint32_t) * n));
+    HIP_TRY(dm.get(missed, sizeof(uint32_t) * n));
+    HIP_TRY(ds.get(slack, sizeof(float) * n));
+    return CASTER_HIP_OK;
+}
+
 }  // extern "C"
+
+// ------------------------------------------------------------------ RCCL reduce
+// RCCL is opened at run time, so that the library loads (and everything but this entry point works)
+// in processes and on machines without it, and so that a process which already holds an RCCL (a
+// PyTorch process) uses that one.
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::vector<int> devices;           // the communicators below were made for these devices, in this order
+    std::vector<ncclComm_t> comms;
+};
+std::mutex g_rccl_mutex;
+Rccl g_rccl;
+
+int rccl_open()
+{
+    if (g_rccl.handle) return CASTER_HIP_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (!h) return fail(CASTER_HIP_ERR_DEVICE, "RCCL not found (librccl.so.1): %s", dlerror());
+#define RCCL_SYM(field, name)                                                             \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name));                 \
+    if (!g_rccl.field) return fail(CASTER_HIP_ERR_DEVICE, "RCCL symbol %s not found", name)
+    RCCL_SYM(CommInitAll, "ncclCommInitAll");
+    RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(Reduce, "ncclReduce");
+    RCCL_SYM(GroupStart, "ncclGroupStart");
+    RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RCCL_SYM
+    g_rccl.handle = h;
+    return CASTER_HIP_OK;
+}
+
+#define RCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess)                                                                      \
+            return fail(CASTER_HIP_ERR_DEVICE, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));  \
+    } while (0)
+
+}  // namespace
+
+extern "C" int caster_hip_reduce(caster_hip_ctx* const* ctxs, float* const* accum_dev, int n, size_t n_floats)
+{
+    if (!ctxs || !accum_dev || n <= 0) return fail(CASTER_HIP_ERR_ARG, "NULL argument or n <= 0");
+    std::vector<int> devices((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        if (!ctxs[k] || !accum_dev[k]) return fail(CASTER_HIP_ERR_ARG, "context or buffer %d is NULL", k);
+        devices[(size_t)k] = ctxs[k]->device;
+        for (int j = 0; j < k; ++j)
+            if (devices[(size_t)j] == devices[(size_t)k])
+                return fail(CASTER_HIP_ERR_ARG, "contexts %d and %d are on the same device %d: sum those with "
+                                                "caster_hip_add_from_device, RCCL wants one rank per GPU", j, k, devices[(size_t)k]);
+    }
+    if (n_floats == 0) return CASTER_HIP_OK;
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    int rc = rccl_open();
+    if (rc) return rc;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    if (g_rccl.devices != devices) {
+        for (ncclComm_t c : g_rccl.comms) (void)g_rccl.CommDestroy(c);
+        g_rccl.comms.assign((size_t)n, nullptr);
+        g_rccl.devices.clear();
+        RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms.data(), n, devices.data()));
+        g_rccl.devices = devices;
+    }
+    // one rank per GPU, all driven from this thread: the calls of a group are issued together
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int k = 0; k < n; ++k) {
+        if (hipSetDevice(devices[(size_t)k]) != hipSuccess) {
+            (void)g_rccl.GroupEnd();
+            if (prev >= 0) (void)hipSetDevice(prev);
+            return fail(CASTER_HIP_ERR_DEVICE, "hipSetDevice(%d) failed", devices[(size_t)k]);
+        }
+        const ncclResult_t r = g_rccl.Reduce(accum_dev[k], accum_dev[k], n_floats, ncclFloat32, ncclSum, 0,
+                                             g_rccl.comms[(size_t)k], ctxs[k]->stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            if (prev >= 0) (void)hipSetDevice(prev);
+            return fail(CASTER_HIP_ERR_DEVICE, "ncclReduce on device %d failed: %s", devices[(size_t)k], g_rccl.GetErrorString(r));
+        }
+    }
+    const ncclResult_t r = g_rccl.GroupEnd();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (r != ncclSuccess) return fail(CASTER_HIP_ERR_DEVICE, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(r));
+    return CASTER_HIP_OK;
+}

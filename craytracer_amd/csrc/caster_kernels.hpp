@@ -228,6 +228,32 @@ __global__ void CASTER_NAME(k_test_texture_)(SceneDev sd, int n, const int32_t* 
     rgb3[3 * k] = c.x; rgb3[3 * k + 1] = c.y; rgb3[3 * k + 2] = c.z;
 }
 
+// The small vector and optics functions of src/common.c and get_uv_coord of src/material.c, one
+// item per thread: in8 holds up to eight floats of arguments, out3 up to three of results.
+//   fn 0 reflectance(cosine, ratio)                 common.c:170-175   -> out[0]
+//   fn 1 v3_f32_refract(unit_v, n, ratio), cos_theta as material.c:30 hands it in (in[7])   common.c:163-168 -> out[0..2]
+//   fn 2 v3_f32_reflect(v, n)                        common.c:158-161   -> out[0..2]
+//   fn 3 get_uv_coord of a point on the unit sphere  material.c:45-56   -> out[0..1]
+//   fn 4 v3_f32_near_zero(v)                         common.c:152-156   -> out[0] = 0 or 1
+//   fn 5 v3_f32_to_unit(v)                           common.c:89-97     -> out[0..2]
+__global__ void CASTER_NAME(k_test_math_)(int fn, int n, const float* in8, float* out3)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* a = in8 + 8 * (size_t)k;
+    V3 r = mk(0.0f, 0.0f, 0.0f);
+    switch (fn) {
+    case 0: r.x = reflectance(a[0], a[1]); break;
+    case 1: r = refract(mk(a[0], a[1], a[2]), mk(a[3], a[4], a[5]), a[6], a[7]); break;
+    case 2: r = reflect(mk(a[0], a[1], a[2]), mk(a[3], a[4], a[5])); break;
+    case 3: { const V2 uv = get_uv_coord_sphere(mk(a[0], a[1], a[2])); r.x = uv.u; r.y = uv.v; break; }
+    case 4: r.x = near_zero(mk(a[0], a[1], a[2])) ? 1.0f : 0.0f; break;
+    case 5: r = to_unit(mk(a[0], a[1], a[2])); break;
+    default: break;
+    }
+    out3[3 * k] = r.x; out3[3 * k + 1] = r.y; out3[3 * k + 2] = r.z;
+}
+
 #if defined(CASTER_STATS) || defined(CASTER_TIMERS)
 extern "C" void CASTER_NAME(caster_debug_stats_)(unsigned long long* out32, int reset)
 {
@@ -293,6 +319,11 @@ hipError_t CASTER_NAME(launch_test_texture_)(const SceneDev& sc, int n, const in
                                              const float* p3, float* rgb3, hipStream_t st)
 {
     hipLaunchKernelGGL(CASTER_NAME(k_test_texture_), grid_for(n), dim3(256), 0, st, sc, n, mat, uv2, p3, rgb3);
+    return hipGetLastError();
+}
+hipError_t CASTER_NAME(launch_test_math_)(int fn, int n, const float* in8, float* out3, hipStream_t st)
+{
+    hipLaunchKernelGGL(CASTER_NAME(k_test_math_), grid_for(n), dim3(256), 0, st, fn, n, in8, out3);
     return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ constexpr float kFilterMarginFast = 2.5e-6f;
 // half-precision operands and of the matrix unit's accumulation to those margins.
 constexpr float kFilterMarginMfmaExtra = 3.0e-5f;
 constexpr int kMfmaMinSpheres = 33;   // below this the vector loop is as fast or faster (measured: equal at 32, 1.4 x slower at 256)
+constexpr int kSphTile = 512;         // spheres per tile: their exact image (8 KiB) is staged in LDS
 
 struct SceneDev {
     const float4* sph;       // cx, cy, cz, r            (list order among spheres)
@@ -48,6 +49,21 @@ struct SceneDev {
     int always[kMaxAlways];  // their indices
 };
 
+// The sphere loop of a launch: the packed vector filter with the exact sphere image in LDS, the
+// same streaming the image through LDS in tiles (more than kSphTile spheres), or the matrix-core
+// filter with the exact image in LDS (up to kSphTile spheres) or in device memory (more), for
+// scenes that qualify.
+enum LoopKind { kLoopVector = 0, kLoopVectorTiled = 1, kLoopMatrix = 2, kLoopMatrixLarge = 3 };
+
+// The one rule that picks the loop, used by the launcher and reported by caster_hip_render_info.
+// `strict` indexes the per-mode tables (0 fast, 1 strict).
+inline int pick_loop_kind(const SceneDev& s, int strict)
+{
+    const bool large = s.n_sph > kSphTile;
+    const bool matrix = s.n_sph >= kMfmaMinSpheres && s.mfma_blocks > 0 && s.mfma_tab[strict] != nullptr;
+    return matrix ? (large ? kLoopMatrixLarge : kLoopMatrix) : (large ? kLoopVectorTiled : kLoopVector);
+}
+
 constexpr int kMaxChunks = 256;
 
 struct RenderArgs {
@@ -62,6 +78,7 @@ struct RenderArgs {
     unsigned long long* fixed; // width * height * 4 fixed-point sums (2^-32 units), zero at launch
     unsigned long long* rays;
     unsigned int* queue;     // work-unit queue head, zero at launch
+    unsigned long long* trips; // wave trips through the sphere loop (128 ray slots each), zero at launch
     int n_units;             // filled in by the launcher
     int lds_spheres;         // float4 slots per sphere image in LDS (filled in by the launcher)
 };
@@ -88,6 +105,11 @@ struct RenderArgs {
                                         float* out6, int32_t* draws, hipStream_t st);             \
     hipError_t launch_test_texture_##SFX(const SceneDev& sc, int n, const int32_t* mat,           \
                                          const float* uv2, const float* p3, float* rgb3,          \
+                                         hipStream_t st);                                         \
+    hipError_t launch_test_math_##SFX(int fn, int n, const float* in8, float* out3,               \
+                                      hipStream_t st);                                            \
+    hipError_t launch_filter_audit_##SFX(const SceneDev& sc, int n, const float* ray6,            \
+                                         uint32_t* accepted, uint32_t* missed, float* slack,      \
                                          hipStream_t st);
 
 CASTER_DECLARE_LAUNCHERS(strict)

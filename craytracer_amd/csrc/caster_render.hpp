@@ -42,7 +42,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int kBlock = 256;                 // 4 waves
 constexpr int kWaves = kBlock / 64;
-constexpr int kSphTile = 512;               // spheres per tile: their exact image (8 KiB) is staged in LDS
 constexpr int kListCap = 16;                // candidate list entries per lane (u16 each) before the lists are worked off
 constexpr int kTileW = 8, kTileH = 8;       // pixels per work unit
 
@@ -966,11 +965,6 @@ CDEV void swap_slots(Slot& a, Slot& b)
 #ifndef CASTER_MATRIX_BLOCKS_PER_CU
 #define CASTER_MATRIX_BLOCKS_PER_CU 4
 #endif
-// The sphere loop of a launch: the packed vector filter with the exact sphere image in LDS, the
-// same streaming the image through LDS in tiles (more than kSphTile spheres), or the matrix-core
-// filter with the exact image in LDS (up to kSphTile spheres) or in device memory (more), for
-// scenes that qualify.
-enum LoopKind { kLoopVector = 0, kLoopVectorTiled = 1, kLoopMatrix = 2, kLoopMatrixLarge = 3 };
 constexpr int lds_fixed_bytes(int kind)
 {
     return (int)sizeof(unsigned long long) * kWaves * kAccStride +
@@ -1023,6 +1017,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     park(sa);
     park(sb);
     unsigned int rays = 0;
+    unsigned int trips = 0;                     // wave-uniform
     float closestA = kTMax, closestB = kTMax;
     int bestA = -1, bestB = -1;
 
@@ -1106,6 +1101,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         }
         CASTER_STAT(0);
         tm.trip();
+        ++trips;
         const unsigned long long t_isect = tm.now();
         closestA = sa.tmax; closestB = sb.tmax;     // a root equal to tmax is still accepted
         bestA = bestB = -1;
@@ -1140,6 +1136,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     unsigned int wrays = rays;
     for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
     if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
+    if (lane == 0 && trips) atomicAdd(a.trips, (unsigned long long)trips);
     tm.report(wave, __shfl(wrays, 0, 64));
 }
 
@@ -1158,9 +1155,7 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     const long long units = (long long)tiles_x * tiles_y * a.n_chunks;
     if (units <= 0 || units > 0x7fffffffLL) return hipErrorInvalidValue;
     a.n_units = (int)units;
-    const bool large = a.scene.n_sph > kSphTile;
-    const bool matrix = a.scene.n_sph >= kMfmaMinSpheres && a.scene.mfma_blocks > 0 && a.scene.mfma_tab[CASTER_STRICT] != nullptr;
-    const int kind = matrix ? (large ? kLoopMatrixLarge : kLoopMatrix) : (large ? kLoopVectorTiled : kLoopVector);
+    const int kind = pick_loop_kind(a.scene, CASTER_STRICT);
     a.lds_spheres = kind == kLoopMatrixLarge ? 0 : lds_sphere_slots(a.scene.n_sph);
     const size_t lds_bytes = lds_fixed_bytes(kind) + sizeof(float4) * (size_t)a.lds_spheres +
                              (a.scene.noise_vec ? kNoiseLdsBytes : 0);
@@ -1267,6 +1262,156 @@ hipError_t CASTER_NAME(launch_test_trace_)(const SceneDev& sc, int n, const floa
     const int per_block = kBlock * 2;
     hipLaunchKernelGGL(CASTER_NAME(k_test_trace_), dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), 0,
                        st, sc, n, ray6, hit, t, p3, n3, face, mat);
+    return hipGetLastError();
+}
+
+// ---- filter audit ----------------------------------------------------------
+// The conservative sphere filter must never reject a pair the exact test accepts: a false
+// negative silently drops a hit.  This kernel takes that from belief to a count.  For every ray
+// and every sphere that goes through the filter (not the directly tested ones) it runs the exact
+// test (candidate_root: the reference's root arithmetic) and evaluates the filter exactly as the
+// render kernel does -- the packed vector form, or the real matrix instructions on the real
+// operand table -- and reports per ray: pairs the exact test accepts, accepted pairs the filter
+// rejected (must be 0), and the smallest slack (key - threshold) / (|o'|^2 + |c'|^2 + r^2) over the
+// accepted pairs: a dimensionless number to hold against the filter's margin g -- the filter
+// errs by (g - slack) on a grazing pair, and fails when that reaches g.
+CDEV int ordered_bits(float x) { const int i = __float_as_int(x); return i < 0 ? (i ^ 0x7fffffff) : i; }
+CDEV float ordered_float(int i) { return __int_as_float(i < 0 ? (i ^ 0x7fffffff) : i); }
+
+struct AuditLds {
+    unsigned int accepted[kWaves][128];
+    unsigned int missed[kWaves][128];
+    int slack[kWaves][128];             // ordered_bits of the smallest slack
+};
+
+CDEV bool audit_listed(const SceneDev& sd, int k)
+{
+    bool direct = false;
+    for (int h = 0; h < sd.n_always; ++h) direct |= (sd.always[h] == k);
+    return k < sd.n_sph && !direct;
+}
+
+CDEV void audit_note(AuditLds* al, int wave, int ray, bool candidate, float slack)
+{
+    atomicAdd(&al->accepted[wave][ray], 1u);
+    if (!candidate) atomicAdd(&al->missed[wave][ray], 1u);
+    atomicMin(&al->slack[wave][ray], ordered_bits(slack));
+}
+
+// One column block of the wave against one sphere block, audited.  CB as in mfma_column.
+template <int CB>
+CDEV void audit_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int blk, const SceneDev& sd, const SceneView& sc,
+                       const Slot& s, bool valid, float oo_scaled, const float3 ref, AuditLds* al, int wave)
+{
+    f16x acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc, 0, 0, 0);
+    const int lane = threadIdx.x & 63;
+    const int owner = 32 * (CB & 1) + (lane & 31);
+    V3 o, d;
+    o.x = fetch(owner, s.o.x); o.y = fetch(owner, s.o.y); o.z = fetch(owner, s.o.z);
+    d.x = fetch(owner, s.d.x); d.y = fetch(owner, s.d.y); d.z = fetch(owner, s.d.z);
+    const float aa = fetch(owner, s.aa), tmin = fetch(owner, s.tmin);
+    const float oo = fetch(owner, oo_scaled);
+    const bool ok = fetch(owner, valid ? 1.0f : 0.0f) != 0.0f;
+    const int ray = (CB >> 1) * 64 + owner;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int k = blk * 32 + (v >> 2) * 8 + (lane >> 5) * 4 + (v & 3);
+        if (!ok || !audit_listed(sd, k)) continue;
+        const float4 sp = sc.sph[k];
+        float t;
+        if (!candidate_root(exact_image(sp), o, d, aa, tmin, t)) continue;
+        const float cx = (sp.x - ref.x) * sd.mfma_scale, cy = (sp.y - ref.y) * sd.mfma_scale, cz = (sp.z - ref.z) * sd.mfma_scale;
+        const float rs = sp.w * sd.mfma_scale;
+        const float scale = oo + ((cx * cx + cy * cy + cz * cz) + rs * rs);
+        // the accumulator holds threshold - key: a set sign bit is a candidate
+        audit_note(al, wave, ray, (__float_as_int(acc[v]) < 0), -acc[v] / scale);
+    }
+}
+
+__global__ __launch_bounds__(kBlock, 2)
+void CASTER_NAME(k_filter_audit_)(SceneDev sd, int n, const float* ray6, uint32_t* accepted, uint32_t* missed, float* slack)
+{
+    __shared__ AuditLds s_audit;
+    const SceneView sc = view_of(sd);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    for (int k = lane; k < 128; k += 64) {
+        s_audit.accepted[wave][k] = 0u;
+        s_audit.missed[wave][k] = 0u;
+        s_audit.slack[wave][k] = ordered_bits(__builtin_inff());
+    }
+    __syncthreads();
+    const float3 ref = make_float3(sd.ref[0], sd.ref[1], sd.ref[2]);
+    const int i0 = (blockIdx.x * kBlock + threadIdx.x) * 2;
+    Slot sl[2];
+    for (int k = 0; k < 2; ++k) {
+        park(sl[k]);
+        if (i0 + k < n) {
+            const float* q = ray6 + 6 * (size_t)(i0 + k);
+            Ray r;
+            r.o = mk(q[0], q[1], q[2]);
+            r.d = mk(q[3], q[4], q[5]);
+            set_ray(sl[k], r);
+            sl[k].alive = true;
+        }
+    }
+    const bool matrix = sd.mfma_blocks > 0 && sc.mfma_tab != nullptr;
+    if (matrix) {
+        const MfmaRays mr = pack_rays_mfma(sl[0], sl[1], ref, sd.mfma_scale);
+        float oo[2];
+        for (int k = 0; k < 2; ++k) {
+            const float qx = (sl[k].o.x - ref.x) * sd.mfma_scale, qy = (sl[k].o.y - ref.y) * sd.mfma_scale,
+                        qz = (sl[k].o.z - ref.z) * sd.mfma_scale;
+            oo[k] = qx * qx + qy * qy + qz * qz;
+        }
+        const bool validA = sl[0].alive && mr.finiteA, validB = sl[1].alive && mr.finiteB;
+        const uint4* tab = sc.mfma_tab + lane;
+#pragma unroll 1
+        for (int blk = 0; blk < sd.mfma_blocks; ++blk) {
+            const h8 A0 = __builtin_bit_cast(h8, tab[blk * 128]), A1 = __builtin_bit_cast(h8, tab[blk * 128 + 64]);
+            audit_column<0>(A0, A1, mr.b00, mr.b01, blk, sd, sc, sl[0], validA, oo[0], ref, &s_audit, wave);
+            audit_column<1>(A0, A1, mr.b10, mr.b11, blk, sd, sc, sl[0], validA, oo[0], ref, &s_audit, wave);
+            audit_column<2>(A0, A1, mr.b20, mr.b21, blk, sd, sc, sl[1], validB, oo[1], ref, &s_audit, wave);
+            audit_column<3>(A0, A1, mr.b30, mr.b31, blk, sd, sc, sl[1], validB, oo[1], ref, &s_audit, wave);
+        }
+    } else {
+        const PairRays pr = pack_rays(sl[0], sl[1], ref);
+        const f2 qx = f2{sl[0].o.x, sl[1].o.x} - splat(ref.x);
+        const f2 qy = f2{sl[0].o.y, sl[1].o.y} - splat(ref.y);
+        const f2 qz = f2{sl[0].o.z, sl[1].o.z} - splat(ref.z);
+        const f2 oo = qx * qx + qy * qy + qz * qz;
+        filter_ptr src = (filter_ptr)sc.filter_img;
+#pragma unroll 1
+        for (int k = 0; k < sc.n_sph; ++k) {
+            if (!audit_listed(sd, k)) continue;                 // wave-uniform
+            const f2 key = candidate_key(pr, entry(src, k));
+            const float4 sp = sc.sph[k];
+            const float cx = sp.x - ref.x, cy = sp.y - ref.y, cz = sp.z - ref.z;
+            const float cc = (cx * cx + cy * cy + cz * cz) + sp.w * sp.w;
+            float t;
+            if (sl[0].alive && pr.finiteA && candidate_root(exact_image(sp), sl[0].o, sl[0].d, sl[0].aa, sl[0].tmin, t))
+                audit_note(&s_audit, wave, lane, key.x >= pr.thrA, (key.x - pr.thrA) / (oo.x + cc));
+            if (sl[1].alive && pr.finiteB && candidate_root(exact_image(sp), sl[1].o, sl[1].d, sl[1].aa, sl[1].tmin, t))
+                audit_note(&s_audit, wave, 64 + lane, key.y >= pr.thrB, (key.y - pr.thrB) / (oo.y + cc));
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < 2; ++k) {
+        if (i0 + k >= n) continue;
+        accepted[i0 + k] = s_audit.accepted[wave][k * 64 + lane];
+        missed[i0 + k] = s_audit.missed[wave][k * 64 + lane];
+        slack[i0 + k] = ordered_float(s_audit.slack[wave][k * 64 + lane]);
+    }
+}
+
+hipError_t CASTER_NAME(launch_filter_audit_)(const SceneDev& sc, int n, const float* ray6, uint32_t* accepted,
+                                             uint32_t* missed, float* slack, hipStream_t st)
+{
+    const int per_block = kBlock * 2;
+    hipLaunchKernelGGL(CASTER_NAME(k_filter_audit_), dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kBlock), 0,
+                       st, sc, n, ray6, accepted, missed, slack);
     return hipGetLastError();
 }
 

@@ -140,6 +140,19 @@ int caster_hip_synchronize(caster_hip_ctx* ctx);
  * reproducible sums. */
 int caster_hip_add_from_device(caster_hip_ctx* ctx, float* dst_dev, int src_device, const float* src_dev, size_t n_floats);
 
+/* The sum of the per-GPU sample partitions as one collective: accum_dev[0] (on the device of
+ * ctxs[0]) receives the element-wise sum of accum_dev[0..n-1], n_floats floats each (width*height*4),
+ * through one RCCL ncclReduce(float32, sum, root 0) per context, issued as a group on the contexts'
+ * streams -- over xGMI between the GPUs of a node.  The contexts must sit on n distinct devices
+ * (buffers that share a device are summed with caster_hip_add_from_device first).  Asynchronous like
+ * caster_hip_render: work queued later on the stream of ctxs[0] sees the sum; the other buffers are
+ * unchanged.  The linear sums must be reduced BEFORE the 1/spp scale and the sqrt of
+ * src/dispatcher.c:29-30, which caster_hip_resolve applies afterwards.  The reference has no
+ * counterpart: its threads share one img_buffer and write disjoint row blocks (src/dispatcher.c:12).
+ * RCCL (librccl.so.1) is opened on the first call; without it the call fails with
+ * CASTER_HIP_ERR_DEVICE and nothing else in the library is affected. */
+int caster_hip_reduce(caster_hip_ctx* const* ctxs, float* const* accum_dev, int n, size_t n_floats);
+
 /*
  * The sample loop of job_func (src/dispatcher.c:12-27) for every pixel and the
  * samples [sample_begin, sample_begin + sample_count): linear RGB sums are
@@ -157,6 +170,23 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
  * depth > 0 (src/caster.c:439); kernel_ms = HIP-event time of the path-tracing
  * kernel alone.  Either pointer may be NULL. */
 int caster_hip_render_stats(caster_hip_ctx* ctx, uint64_t* rays, float* kernel_ms);
+
+/* What the last render on this context ran (waits for it), for measurement: the reference publishes
+ * per-thread ray counts and times the same way (src/dispatcher.c:36-40, src/display.c:190-219).
+ * loop_kind: 0 sphere filter on the vector unit, 1 the same with the sphere list streamed through
+ * LDS in tiles, 2 filter on the matrix cores, 3 the same for lists of more than 512 spheres.
+ * wave_trips counts the trips of all waves through the sphere loop: each trip meets 128 ray slots
+ * with every sphere of the list (in the matrix loop: mfma_blocks blocks of 32 spheres x 4 blocks of
+ * 32 rays x 2 v_mfma_f32_32x32x16_f16). */
+typedef struct {
+    int32_t loop_kind;
+    int32_t mfma_blocks;
+    int32_t n_spheres;
+    float kernel_ms;
+    uint64_t rays;
+    uint64_t wave_trips;
+} caster_render_info;
+int caster_hip_render_info(caster_hip_ctx* ctx, caster_render_info* out);
 
 /* src/dispatcher.c:11,29-34 + src/image.c:30-36: x (1.0f/spp), component sqrt,
  * clamp to [0, 0.999], x256, truncate; alpha 0; row y = height-j-1.
@@ -203,6 +233,28 @@ int caster_hip_test_camera_ray(caster_hip_ctx* ctx, uint32_t flags, const caster
 /* texture_get_color_at (src/material.c:65-101) for material mat[k] of the uploaded scene. */
 int caster_hip_test_texture(caster_hip_ctx* ctx, uint32_t flags, int n, const int32_t* mat,
                             const float* uv2, const float* p3, float* rgb3);
+/* The small vector and optics functions, item k reading in8[8k..] and writing out3[3k..]:
+ *   CASTER_MATH_REFLECTANCE  reflectance(cosine = in[0], ratio = in[1])            src/common.c:170-175  -> out[0]
+ *   CASTER_MATH_REFRACT      v3_f32_refract(uv = in[0..2], n = in[3..5], ratio = in[6]) with the
+ *                            cos_theta of src/material.c:30 in in[7]                src/common.c:163-168  -> out[0..2]
+ *   CASTER_MATH_REFLECT      v3_f32_reflect(v = in[0..2], n = in[3..5])             src/common.c:158-161  -> out[0..2]
+ *   CASTER_MATH_UV_SPHERE    get_uv_coord of a sphere's outward normal in[0..2]     src/material.c:45-56  -> out[0..1]
+ *   CASTER_MATH_NEAR_ZERO    v3_f32_near_zero(in[0..2])                             src/common.c:152-156  -> out[0] = 0 or 1
+ *   CASTER_MATH_TO_UNIT      v3_f32_to_unit(in[0..2])                               src/common.c:89-97    -> out[0..2] */
+enum { CASTER_MATH_REFLECTANCE = 0, CASTER_MATH_REFRACT = 1, CASTER_MATH_REFLECT = 2, CASTER_MATH_UV_SPHERE = 3,
+       CASTER_MATH_NEAR_ZERO = 4, CASTER_MATH_TO_UNIT = 5 };
+int caster_hip_test_math(caster_hip_ctx* ctx, uint32_t flags, int fn, int n, const float* in8, float* out3);
+/* Audit of the conservative sphere filter that stands in front of hit_sphere in the render kernel
+ * (src/caster.c:204 tests every sphere; the kernel runs the exact test only on the filter's
+ * candidates, so a filter that rejects a sphere the exact test accepts would drop a hit).  For ray k
+ * and every sphere of the uploaded scene that goes through the filter: accepted[k] = spheres the
+ * exact test reports (any root >= tmin), missed[k] = those of them the filter rejected -- must be 0
+ * -- and slack[k] = the smallest (key - threshold) / (|o'|^2 + |c'|^2 + r^2) over the accepted ones
+ * (+inf if none): the filter's margin g minus its arithmetic error on the most critical pair, to
+ * hold against g.  The filter runs as a render call with these flags would run it: on the matrix
+ * cores where the scene qualifies, on the vector unit otherwise or with CASTER_HIP_VECTOR_LOOP. */
+int caster_hip_filter_audit(caster_hip_ctx* ctx, uint32_t flags, int n, const float* ray6,
+                            uint32_t* accepted, uint32_t* missed, float* slack);
 /* First n 24-bit draws of the stream keyed (seed, pixel, sample). */
 int caster_hip_test_rng(caster_hip_ctx* ctx, uint32_t seed, uint32_t pixel, uint32_t sample,
                         int n, uint32_t* out24);

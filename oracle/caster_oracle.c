@@ -776,3 +776,24 @@ void orc_batch_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32
     for (int k = 0; k < n; k++)
         out24[k] = orc_rng_next24(&g);
 }
+
+/* The small vector and optics functions, array at a time (item k reads in8[8k..], writes out3[3k..]):
+ * 0 reflectance, 1 refract (cos_theta in in[7]), 2 reflect, 3 get_uv_coord of a sphere normal,
+ * 4 near_zero, 5 to_unit.  src/common.c:89-97,152-175, src/material.c:45-56. */
+void orc_batch_math(int fn, int n, const float* in8, float* out3)
+{
+    for (int k = 0; k < n; k++) {
+        const float* a = in8 + 8 * (size_t)k;
+        ov3 r = v3(0.0f, 0.0f, 0.0f);
+        switch (fn) {
+        case 0: r.x = orc_reflectance(a[0], a[1]); break;
+        case 1: r = orc_refract(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), a[6], a[7]); break;
+        case 2: r = orc_reflect(v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5])); break;
+        case 3: { ov2 uv = orc_get_uv_coord_sphere(v3(a[0], a[1], a[2])); r.x = uv.u; r.y = uv.v; break; }
+        case 4: r.x = orc_near_zero(v3(a[0], a[1], a[2])) ? 1.0f : 0.0f; break;
+        case 5: r = orc_to_unit(v3(a[0], a[1], a[2])); break;
+        default: break;
+        }
+        out3[3 * k] = r.x; out3[3 * k + 1] = r.y; out3[3 * k + 2] = r.z;
+    }
+}

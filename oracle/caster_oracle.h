@@ -183,6 +183,7 @@ void orc_batch_camera_ray(const ocam* cam, int n, const float* uv2, uint32_t see
 void orc_batch_texture(const oscene* sc, int n, const int32_t* mat, const float* uv2, const float* p3,
                        float* rgb3);
 void orc_batch_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24);
+void orc_batch_math(int fn, int n, const float* in8, float* out3);
 
 #ifdef __cplusplus
 }

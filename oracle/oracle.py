@@ -219,5 +219,16 @@ def rng(seed, pixel, sample, n):
     return out
 
 
+MATH_REFLECTANCE, MATH_REFRACT, MATH_REFLECT, MATH_UV_SPHERE, MATH_NEAR_ZERO, MATH_TO_UNIT = range(6)
+
+
+def math(fn, in8):
+    """orc_batch_math: item k reads in8[k, :8] and returns out[k, :3] (see caster_oracle.c)."""
+    in8 = _f32(in8, (-1, 8))
+    out = np.zeros((len(in8), 3), np.float32)
+    lib().orc_batch_math(C.c_int(fn), C.c_int(len(in8)), _p(in8), _p(out))
+    return out
+
+
 def reflectance(cosine, ratio) -> float:
     return float(lib().orc_reflectance(C.c_float(cosine), C.c_float(ratio)))
