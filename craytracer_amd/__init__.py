@@ -35,6 +35,7 @@ from .binding import (  # noqa: F401
     make_test_texture,
     bmp_encode,
     reduce,
+    NOALLOC_MAX_PIXELS,
     LOOP_NAMES,
     MATH_REFLECTANCE,
     MATH_REFRACT,

@@ -41,6 +41,7 @@ class _RenderInfo(C.Structure):      # caster_render_info
                 ("rays", C.c_uint64), ("wave_trips", C.c_uint64)]
 
 
+NOALLOC_MAX_PIXELS = 1 << 20         # CASTER_HIP_NOALLOC_MAX_PIXELS
 MATH_REFLECTANCE, MATH_REFRACT, MATH_REFLECT, MATH_UV_SPHERE, MATH_NEAR_ZERO, MATH_TO_UNIT = range(6)
 LOOP_NAMES = {0: "vector", 1: "vector_tiled", 2: "matrix", 3: "matrix_large"}
 
@@ -368,6 +369,17 @@ class CasterHip:
                 C.c_int(max_depth), C.c_uint32(seed), C.c_uint32((STRICT if strict else 0) | (VECTOR_LOOP if vector_loop else 0)), C.c_void_p(accum_ptr),
             ),
             "caster_hip_render",
+        )
+
+    def render_noalloc(self, cam, width, height, sample_begin, sample_count, max_depth, seed, accum_ptr: int, strict=False, vector_loop=False):
+        """caster_hip_render_noalloc: the same render out of the library's static scratch (no device allocation)."""
+        cam = _f32(cam, (19,))
+        _check(
+            self._lib.caster_hip_render_noalloc(
+                self._ctx, _ptr(cam), C.c_int(width), C.c_int(height), C.c_int(sample_begin), C.c_int(sample_count),
+                C.c_int(max_depth), C.c_uint32(seed), C.c_uint32((STRICT if strict else 0) | (VECTOR_LOOP if vector_loop else 0)), C.c_void_p(accum_ptr),
+            ),
+            "caster_hip_render_noalloc",
         )
 
     def render_info(self) -> dict:

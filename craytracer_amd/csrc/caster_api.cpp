@@ -42,6 +42,20 @@ constexpr int kCounterWords = 4;
 
 }  // namespace
 
+// Scratch of caster_hip_render_noalloc: the counters and the per-pixel fixed-point sums of a call,
+// which caster_hip_render keeps in buffers it allocates.  A file-scope device array: every GPU the
+// library runs on holds its own copy (32 MiB + 32 B) at its own address until the process ends.  In
+// host code the name is only a handle for hipGetSymbolAddress (caster_hip_create asks once per
+// device and keeps the pointer); kernels and hipMemsetAsync are given that pointer, never the name.
+constexpr size_t kNoAllocMaxPixels = (size_t)CASTER_HIP_NOALLOC_MAX_PIXELS;
+static __device__ __align__(256) unsigned long long scratch[kCounterWords + 4 * kNoAllocMaxPixels];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned long long* g_scratch_ptr[kMaxDevices] = {};    // per device, filled in with that device current
+}  // namespace
+
 struct caster_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -56,6 +70,7 @@ struct caster_hip_ctx {
     unsigned long long* fixed = nullptr;      // per-pixel fixed-point sums of the call in flight
     size_t fixed_bytes = 0;
     unsigned long long* counters = nullptr;   // kCounterWords words: [0] rays, [1] low word: work-unit queue head, [2] wave trips
+    unsigned long long* scratch = nullptr;    // this device's copy of the static scratch array (caster_hip_render_noalloc)
     int resident_blocks = 1024;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool render_pending = false;
@@ -178,6 +193,21 @@ int caster_hip_create(int device, caster_hip_ctx** out)
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         caster_hip_destroy(ctx);
         return fail(CASTER_HIP_ERR_DEVICE, "context allocation on device %d failed", device);
+    }
+    if (device < kMaxDevices) {
+        // the address of this device's copy of the scratch array (the device is current: DeviceGuard above)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device]) {
+            void* p = nullptr;
+            const hipError_t se = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (se != hipSuccess || !p) {
+                caster_hip_destroy(ctx);
+                return fail(CASTER_HIP_ERR_DEVICE, "hipGetSymbolAddress(scratch) on device %d failed: %s", device,
+                            hipGetErrorString(se));
+            }
+            g_scratch_ptr[device] = static_cast<unsigned long long*>(p);
+        }
+        ctx->scratch = g_scratch_ptr[device];
     }
     *out = ctx;
     return CASTER_HIP_OK;
@@ -530,7 +560,8 @@ static int plan_chunks(const caster_hip_ctx* ctx, int width, int height, int sam
 }
 
 // The body of both render entry points.  `fixed` (width * height * 4 words) and `counters`
-// (kCounterWords words) are the call's scratch: the context's own buffers.  Nothing here allocates.
+// (kCounterWords words) are the call's scratch: the context's own buffers, or this device's copy of
+// the static array.  Nothing here allocates.
 static int render_on(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height, int sample_begin,
                      int sample_count, int max_depth, uint32_t seed, uint32_t flags, float* accum_dev,
                      unsigned long long* fixed, unsigned long long* counters)
@@ -609,6 +640,22 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     }
     return render_on(ctx, cam, width, height, sample_begin, sample_count, max_depth, seed, flags, accum_dev,
                      ctx->fixed, ctx->counters);
+}
+
+int caster_hip_render_noalloc(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height,
+                              int sample_begin, int sample_count, int max_depth,
+                              uint32_t seed, uint32_t flags, float* accum_dev)
+{
+    int rc = check_render_args(ctx, cam, width, height, sample_begin, sample_count, flags, accum_dev);
+    if (rc) return rc;
+    if ((size_t)width * (size_t)height > kNoAllocMaxPixels)
+        return fail(CASTER_HIP_ERR_ARG, "caster_hip_render_noalloc: %dx%d = %zu pixels exceed the static scratch of %zu pixels; "
+                                        "use caster_hip_render or render the frame in parts",
+                    width, height, (size_t)width * (size_t)height, kNoAllocMaxPixels);
+    if (!ctx->scratch) return fail(CASTER_HIP_ERR_STATE, "no scratch address for device %d", ctx->device);
+    DeviceGuard guard(ctx->device);
+    return render_on(ctx, cam, width, height, sample_begin, sample_count, max_depth, seed, flags, accum_dev,
+                     ctx->scratch + kCounterWords, ctx->scratch);
 }
 
 int caster_hip_add_from_device(caster_hip_ctx* ctx, float* dst_dev, int src_device, const float* src_dev, size_t n_floats)
