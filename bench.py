@@ -29,6 +29,10 @@ FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X vector FP32, 256 CU x 256 flop/clk x
 F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense FP16 matrix peak (no sparsity)
 
 
+MFMA_FLOPS = 2 * 32 * 32 * 16      # one v_mfma_f32_32x32x16_f16
+VECTOR_FILTER_FLOPS_PER_PAIR = 13  # the packed filter: 1 multiply + 6 fused multiply-adds per (ray, sphere)
+
+
 def flops_per_ray(n_spheres: int, n_rects: int) -> int:
     """Algorithmic work of one ray: 18 flop per ray-sphere test (oc 3, oc.d 5, oc.oc 5, r*r and
     subtract 2, discriminant 3; FMA counts 2), 12 per rect test, and a nominal 100 for the
@@ -85,6 +89,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vector-steps", type=int, default=2,
+                    help="frames of the second leg (sphere filter on the vector unit), timed outside the main region; 0 = skip")
     args = ap.parse_args()
 
     import torch
@@ -128,18 +134,23 @@ def main():
 
     kernel_ms = []
     rays_step = [0]
+    info_step = [None]
 
-    def one_step():
+    def one_step(vector_loop=False):
+        # everything of a frame is queued on one stream without a host wait in between: clear, render,
+        # sum over ranks (RCCL), resolve; the host then waits once for the frame
         accum.zero_()
         begin, count = render_frame(
-            lambda b, c: gpu.render(cam, W, H, b, c, args.depth, args.seed, accum.data_ptr(), strict=strict),
+            lambda b, c: gpu.render(cam, W, H, b, c, args.depth, args.seed, accum.data_ptr(), strict=strict,
+                                    vector_loop=vector_loop),
             (lambda: dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)) if world > 1 else None,
             SPP, world, rank)
         if rank == 0:
             gpu.resolve_dev(accum.data_ptr(), W, H, SPP, rgba.data_ptr())
-        rays, ms = gpu.render_stats()          # waits for this rank's frame: the frame boundary
-        rays_step[0] = rays
-        kernel_ms.append(ms)
+        info = gpu.render_info()               # waits for this rank's frame: the frame boundary
+        rays_step[0] = info["rays"]
+        info_step[0] = info
+        kernel_ms.append(info["kernel_ms"])    # HIP events on the kernel's own stream, around the kernel alone
 
     for _ in range(args.warmup):
         one_step()
@@ -150,10 +161,27 @@ def main():
         one_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    main_info = info_step[0]
+    main_kernel_ms = float(np.mean(kernel_ms))
+
+    # Second leg, outside the timed region, one GPU only: the same frame with the sphere filter on the
+    # vector unit (CASTER_HIP_VECTOR_LOOP), the form whose bound is the FP32 vector peak.
+    vector_leg = None
+    if world == 1 and args.vector_steps > 0:
+        one_step(vector_loop=True)
+        kernel_ms.clear()
+        torch.cuda.synchronize(dev)
+        tv = time.perf_counter()
+        for _ in range(args.vector_steps):
+            one_step(vector_loop=True)
+        torch.cuda.synchronize(dev)
+        tv = time.perf_counter() - tv
+        vector_leg = (info_step[0], float(np.mean(kernel_ms)), tv / args.vector_steps * 1e3)
+        rays_step[0] = main_info["rays"]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     r = torch.tensor([float(rays_step[0])], dtype=torch.float64, device=dev)
-    k = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+    k = torch.tensor([main_kernel_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
@@ -166,10 +194,18 @@ def main():
         ns, nr = fs.n_spheres, fs.n_rects
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_frame * args.steps / elapsed * 1e-6
-        # roofline of the dominant kernel (render_kernel_*): algorithmic flops of the rays one launch
-        # traces on this rank / its HIP-event duration
-        rank_rays = rays_step[0]
-        achieved = rank_rays * flops_per_ray(ns, nr) / (np.mean(kernel_ms) * 1e-3) * 1e-12
+        workload = f"rtiow_final_scene {W}x{H} {SPP}spp depth{args.depth}"
+        roof = roofline_of(main_info, main_kernel_ms, args.mode, ns, nr)
+        roof["traffic"] = recorded_traffic(workload, args.mode, world)
+        roof["counters"] = recorded_counters(workload, args.mode, world, main_info["loop"])
+        if vector_leg is not None:
+            v_info, v_ms, v_wall_ms = vector_leg
+            vr = roofline_of(v_info, v_ms, args.mode, ns, nr)
+            vr["ms_per_frame"] = round(v_wall_ms, 3)
+            vr["mrays_per_s"] = round(v_info["rays"] / (v_wall_ms * 1e-3) * 1e-6, 2)
+            vr["steps"] = args.vector_steps
+            vr["counters"] = recorded_counters(workload, args.mode, world, v_info["loop"])
+            roof["vector_loop"] = vr
         out = {
             "metric": "Mrays/s at 1080p 500spp (RTIOW final scene, depth 50, brute-force closest hit)",
             "value": round(value, 2),
@@ -184,7 +220,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"rtiow_final_scene {W}x{H} {SPP}spp depth{args.depth}",
+                "workload": workload,
                 "objects": int(len(fs.objects)),
                 "arithmetic_mode": args.mode,
                 "parallelism": f"sample-partition x{world}" + (" + RCCL sum-reduce to rank 0" if world > 1 else ""),
@@ -193,21 +229,7 @@ def main():
             "ms_per_frame": round(ms_per_step, 3),
             "rays_per_frame": rays_frame,
             "kernel_ms_per_frame": round(kernel_ms_avg, 3),
-            "roofline": {
-                "bound": "valu_fp32",
-                "achieved": round(float(achieved), 3),
-                "peak": FP32_VALU_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(float(achieved) / FP32_VALU_PEAK_TFLOPS, 4),
-                "traffic": recorded_traffic(f"rtiow_final_scene {W}x{H} {SPP}spp depth{args.depth}", args.mode, world),
-                "kernel": f"caster::render_kernel_{args.mode}<2>",
-                "flops_per_ray": flops_per_ray(ns, nr),
-                "note": "achieved = algorithmic flops (18 per ray-sphere test of the reference's brute-force loop) against the FP32 "
-                        "vector peak, the bound of that algorithm as written; the conservative filter's products now run on the "
-                        "matrix cores (see matrix_cores), so the figure is not capped by the vector peak; the kernel itself is "
-                        "limited by vector-instruction issue (sign masks, exact tests, shading)",
-                "matrix_cores": matrix_core_use(rank_rays, ns, float(np.mean(kernel_ms))),
-            },
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fs, cam, W, H, args.depth, args.seed, args.cpu_seconds)
@@ -218,33 +240,88 @@ def main():
         dist.destroy_process_group()
 
 
-def matrix_core_use(rays, n_spheres, kernel_ms):
-    """Matrix-core work of the candidate filter: every ray meets every block of 32 spheres with two
-    v_mfma_f32_32x32x16_f16 per 32 x 32 keys, 64 flops per key."""
-    if n_spheres > 512:
-        return None                      # the vector loop renders larger scenes
-    rows = (n_spheres + 31) // 32 * 32
-    executed = rays * rows * 64.0 / (kernel_ms * 1e-3) * 1e-12
-    return {"executed": round(executed, 1), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "dtype": "f16 operands, f32 accumulate",
-            "frac": round(executed / F16_MFMA_PEAK_TFLOPS, 4)}
+def roofline_of(info, kernel_ms, mode, n_spheres, n_rects):
+    """Roofline entry of one launch of the render kernel, from what the launch itself reports
+    (caster_hip_render_info: which sphere loop ran, wave trips, rays) and its HIP-event duration.
+
+    Executed work, so the fraction cannot exceed 1:
+      * matrix loop: every wave trip meets 4 blocks of 32 rays with every block of 32 spheres through two
+        v_mfma_f32_32x32x16_f16 -> trips x blocks x 4 x 2 x 32768 flop, against the dense FP16 matrix peak;
+      * vector loop: every trip evaluates the packed filter (1 multiply + 6 FMAs = 13 flop) for 128 ray
+        slots and every sphere of the padded list, against the FP32 vector peak.
+    The work of the reference's loop as written (18 flop per ray-sphere test) is reported beside it as
+    algorithmic_equivalent; it is not a fraction of any unit of this kernel."""
+    sec = kernel_ms * 1e-3
+    trips = info["wave_trips"]
+    alg = info["rays"] * flops_per_ray(n_spheres, n_rects) / sec * 1e-12
+    if info["loop_kind"] >= 2:
+        executed = trips * info["mfma_blocks"] * 4 * 2 * MFMA_FLOPS / sec * 1e-12
+        bound, peak, kind = "mfma", F16_MFMA_PEAK_TFLOPS, "<2>" if info["loop_kind"] == 2 else "<3>"
+        note = ("executed flops of the conservative sphere filter on the matrix cores (f16 operands, f32 accumulate) "
+                "against the dense f16 matrix peak; the kernel as a whole is co-bound by vector-instruction issue "
+                "(exact tests, shading, path starts): see counters")
+    else:
+        padded = (n_spheres + 7) // 8 * 8
+        executed = trips * 128 * padded * VECTOR_FILTER_FLOPS_PER_PAIR / sec * 1e-12
+        bound, peak, kind = "valu_fp32", FP32_VALU_PEAK_TFLOPS, "<0>" if info["loop_kind"] == 0 else "<1>"
+        note = ("executed flops of the packed FP32 sphere filter (13 per ray-sphere pair) against the FP32 vector peak; "
+                "algorithmic_equivalent counts the 18 flop of the reference's test per pair")
+    return {
+        "bound": bound,
+        "achieved": round(float(executed), 3),
+        "peak": peak,
+        "unit": "TFLOP/s",
+        "frac": round(float(executed) / peak, 4),
+        "traffic": None,
+        "kernel": f"caster::render_kernel_{mode}{kind}",
+        "loop": info["loop"],
+        "kernel_ms": round(kernel_ms, 3),
+        "wave_trips": int(trips),
+        "slots_in_use": round(info["rays"] / max(1, trips * 128), 4),
+        "algorithmic_equivalent": {
+            "tflops": round(float(alg), 3), "flops_per_ray": flops_per_ray(n_spheres, n_rects),
+            "of_fp32_vector_peak": round(float(alg) / FP32_VALU_PEAK_TFLOPS, 4),
+        },
+        "note": note,
+    }
+
+
+def _latest_profile(pattern):
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pattern)))
+    for path in reversed(paths):
+        try:
+            with open(path) as f:
+                yield json.load(f)
+        except (OSError, ValueError):
+            continue
+
+
+def recorded_counters(workload, mode, world, loop):
+    """Hardware-counter figures of this workload's render kernel (vector-instruction issue, active
+    lanes, FP32 flops executed, matrix-pipe busy).  Counters cannot be read inside a timed run: these
+    are the ones recorded with rocprofv3 --pmc for this exact workload, mode and loop
+    (tools/pmc_summary.py -> profiles/*pmc_summary*.json); None for anything else."""
+    if world != 1:
+        return None
+    for rec in _latest_profile("*pmc_summary*.json"):
+        for entry in rec.get("kernels", []):
+            if entry.get("workload") == workload and entry.get("arithmetic_mode") == mode and entry.get("loop") == loop:
+                return entry.get("figures")
+    return None
 
 
 def recorded_traffic(workload, mode, world):
     """HBM bytes per launch of the render kernel.  Counters cannot be read from inside a timed run:
     the figure is the one measured with rocprofv3 --pmc passes for this exact workload, kept under
     profiles/ together with how it was taken; None for any other workload."""
-    import glob
-
-    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*hbm_traffic.json")))
-    if not paths:
+    if world != 1:
         return None
-    try:
-        with open(paths[-1]) as f:      # the latest measurement
-            rec = json.load(f)
-    except (OSError, ValueError):
+    for rec in _latest_profile("*hbm_traffic.json"):
+        if rec.get("workload") == workload and rec.get("arithmetic_mode") == mode:
+            return rec.get("bytes_per_launch")
         return None
-    if world == 1 and rec.get("workload") == workload and rec.get("arithmetic_mode") == mode:
-        return rec.get("bytes_per_launch")
     return None
 
 

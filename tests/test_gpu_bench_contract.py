@@ -30,8 +30,15 @@ def test_bench_line_has_the_contract_fields():
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in r, key
-    assert r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["traffic"] is None                       # the recorded traffic belongs to the full-size workload only
+    # executed work against the unit it runs on: a fraction of a peak, never above it
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and r["loop"] == "matrix"
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["wave_trips"] > 0 and 0.5 < r["slots_in_use"] <= 1.0
+    assert r["traffic"] is None and r["counters"] is None    # the recorded counters belong to the full-size workload only
+    v = r["vector_loop"]                              # second leg: the filter on the vector unit, against the FP32 vector peak
+    assert v["bound"] == "valu_fp32" and v["peak"] == 157.3 and v["loop"] == "vector"
+    assert 0.0 < v["frac"] <= 1.0 and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-3
+    assert v["algorithmic_equivalent"]["flops_per_ray"] == 18 * 487 + 100
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s"
     # value = rays of all steps / wall time

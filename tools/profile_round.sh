@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU call's worth of measurement for a round: bench.py, the same under rocprofv3 --kernel-trace --stats,
+# and the counter passes of tools/pmc.sh for both sphere loops.  usage (on the GPU box): bash tools/profile_round.sh <tag>
+set -e
+tag=$1
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd $R
+timeout -k 10 240 python3 bench.py --steps 5 --warmup 1 > $O/bench_strict.json 2> $O/bench_strict.err
+timeout -k 10 240 python3 bench.py --steps 5 --warmup 1 --mode fast --no-cpu-baseline > $O/bench_fast.json 2> $O/bench_fast.err
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err
+cd $R
+BENCH_ARGS="--spp 500 --reps 1 --modes strict" bash tools/pmc.sh gpurun_out/$tag/pmc_matrix --
+BENCH_ARGS="--spp 500 --reps 1 --modes strict --vector-loop" bash tools/pmc.sh gpurun_out/$tag/pmc_vector --
+python3 tools/pmc_summary.py gpurun_out/$tag/pmc_matrix "rtiow_final_scene 1920x1080 500spp depth50" strict matrix \
+    gpurun_out/$tag/pmc_vector "rtiow_final_scene 1920x1080 500spp depth50" strict vector --out gpurun_out/$tag/$tag > $O/pmc_summary.txt
+cat $O/bench_strict.json

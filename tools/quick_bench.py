@@ -56,9 +56,11 @@ for mode in args.modes.split(","):
         gpu.synchronize()
         t0 = time.perf_counter()
         gpu.render(cam, args.width, args.height, 0, args.spp, args.depth, 0xC0FFEE, acc, strict=strict, vector_loop=args.vector_loop)
-        rays, ms = gpu.render_stats()
+        info = gpu.render_info()
+        rays, ms = info["rays"], info["kernel_ms"]
         wall = time.perf_counter() - t0
         flops = rays * (18 * ns + 12 * nr + 100)
         print(f"{mode:6s} rep{rep} rays {rays} ({rays / (args.width * args.height * args.spp):.2f}/path) kernel {ms:.2f} ms wall {wall * 1e3:.2f} ms "
-              f"{rays / ms * 1e-3:.1f} Mrays/s  {flops / (ms * 1e-3) / 157.3e12 * 100:.1f}% of FP32 peak", flush=True)
+              f"{rays / ms * 1e-3:.1f} Mrays/s  {flops / (ms * 1e-3) / 157.3e12 * 100:.1f}% of FP32 peak (algorithmic)  "
+              f"loop {info['loop']} blocks {info['mfma_blocks']} trips {info['wave_trips']}", flush=True)
 gpu.free(acc)
