@@ -666,6 +666,10 @@ int caster_hip_add_from_device(caster_hip_ctx* ctx, float* dst_dev, int src_devi
         return fail(CASTER_HIP_ERR_ARG, "source device %d out of range", src_device);
     if (n_floats == 0) return CASTER_HIP_OK;
     DeviceGuard guard(ctx->device);
+    if (src_device == ctx->device) {        // the same GPU: no copy, the add kernel reads the source in place
+        HIP_TRY(caster::launch_add(dst_dev, src_dev, n_floats, ctx->stream));
+        return CASTER_HIP_OK;
+    }
     const size_t bytes = n_floats * sizeof(float);
     if (bytes > ctx->staging_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));

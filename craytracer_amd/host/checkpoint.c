@@ -89,23 +89,35 @@ int crt_ranges_slice(const crt_range* r, int n, i32 first, i32 count, crt_range*
     return m;
 }
 
-/* FNV-1a over the flattened scene tables: a resumed run must render the scene it started with. */
+/* FNV-1a, continued from h. */
+u64 crt_hash_bytes(u64 h, const void* data, size_t n)
+{
+    const u8* p = (const u8*)data;
+    for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+/* Hash of everything of the flattened scene that reaches the GPU -- objects, materials, every image
+ * texture's size and texels, the noise tables: a resumed run must render the scene it started with. */
 u64 crt_flat_hash(const crt_flat_scene* fs)
 {
     u64 h = 1469598103934665603ull;
     if (!fs) return h;
     int n_obj = 0, n_mat = 0, n_img = 0;
     crt_flat_counts(fs, &n_obj, &n_mat, &n_img);
-    const struct { const u8* p; size_t n; } parts[2] = {
-        { (const u8*)crt_flat_objects(fs), (size_t)n_obj * sizeof(caster_object) },
-        { (const u8*)crt_flat_materials(fs), (size_t)n_mat * sizeof(caster_material) },
-    };
-    for (int k = 0; k < 2; k++)
-        for (size_t i = 0; i < parts[k].n; i++) { h ^= parts[k].p[i]; h *= 1099511628211ull; }
+    h = crt_hash_bytes(h, crt_flat_objects(fs), (size_t)n_obj * sizeof(caster_object));
+    h = crt_hash_bytes(h, crt_flat_materials(fs), (size_t)n_mat * sizeof(caster_material));
+    const caster_image* img = (const caster_image*)crt_flat_images(fs);
+    for (int k = 0; k < n_img; k++) {
+        const u32 dims[3] = { img[k].w, img[k].h, img[k].bpp };
+        h = crt_hash_bytes(h, dims, sizeof dims);
+        h = crt_hash_bytes(h, img[k].data, (size_t)img[k].w * img[k].h * img[k].bpp);
+    }
+    if (crt_flat_noise(fs)) h = crt_hash_bytes(h, crt_flat_noise(fs), sizeof(caster_noise));
     return h;
 }
 
-static const char kMagic[8] = { 'C', 'R', 'T', 'A', 'C', 'C', '0', '1' };
+static const char kMagic[8] = { 'C', 'R', 'T', 'A', 'C', 'C', '0', '2' };
 
 int crt_checkpoint_write(const char* path, const crt_checkpoint* cp)
 {

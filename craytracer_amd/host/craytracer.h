@@ -116,6 +116,8 @@ typedef struct {
     i32 atomic_spp_rays_total[MAX_THREADS];    /* rays so far (wraps at 2^31, as the reference's i32 does) */
     u64 rays_total[MAX_THREADS];               /* the same count without the wrap */
     int status;                                /* 0, or the first libcaster_hip error */
+    u64 fence_sum_us;                          /* the fence's sum of the jobs' buffers: wall time ...  */
+    const char* fence_sum_how;                 /* ... and the route it took (static string)            */
 } ray_dispatcher;
 
 ray_dispatcher new_ray_dispatcher(u8 num_threads, u8 blocks, i32 width, i32 height, i32 spp, i32 max_depth,
@@ -135,7 +137,8 @@ void ray_dispatcher_set_jobs(ray_dispatcher* rd, i32 jobs);
  * src/dispatcher.c:6-7).  set_checkpoint: the fence writes the frame's radiance sums and the sample
  * ranges they hold to the file, also after a cancel.  resume: the sums of the file become the start
  * of the frame and the jobs render only the samples of [0, spp) that it lacks; returns 0, or -1 if
- * the file is unreadable or belongs to another frame size, seed, arithmetic mode, depth or scene.
+ * the file is unreadable or belongs to another frame size, seed, arithmetic mode, depth, camera or scene
+ * (objects, materials, texture images, noise tables).
  * Call both before run_jobs. */
 void ray_dispatcher_set_checkpoint(ray_dispatcher* rd, const char* path);
 int ray_dispatcher_resume(ray_dispatcher* rd, const char* path);
@@ -198,7 +201,8 @@ const void* crt_flat_objects(const crt_flat_scene* fs);    /* caster_object[]   
 const void* crt_flat_materials(const crt_flat_scene* fs);  /* caster_material[] */
 const void* crt_flat_images(const crt_flat_scene* fs);     /* caster_image[]    */
 const void* crt_flat_noise(const crt_flat_scene* fs);      /* caster_noise* or NULL */
-u64 crt_flat_hash(const crt_flat_scene* fs);               /* of the object and material tables */
+u64 crt_flat_hash(const crt_flat_scene* fs);               /* of the object, material, image and noise tables */
+u64 crt_hash_bytes(u64 h, const void* data, size_t n);     /* FNV-1a, continued from h */
 
 /* Bytes write_img_buffer_to_file() writes, into out (54 + h*stride bytes). */
 long crt_bmp_encode(const img_buffer* buffer, u8* out);

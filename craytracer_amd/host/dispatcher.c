@@ -24,6 +24,7 @@ typedef struct {
     float* accum_dev;
     int samples_done;
     int status;
+    int thread_started;              /* pthread_create succeeded: the fence joins only these */
     char err[256];
 } gpu_job;
 
@@ -40,6 +41,12 @@ typedef struct {
     crt_checkpoint* resume;          /* sums and sample ranges of an earlier run, or NULL */
     char* checkpoint_path;           /* where the fence writes the frame's checkpoint, or NULL */
 } gpu_backend;
+
+/* Identity of a frame for checkpoints: the scene as uploaded and the camera's 19 floats. */
+static u64 frame_hash(const gpu_backend* be, const ray_dispatcher* rd)
+{
+    return crt_hash_bytes(crt_flat_hash(be->flat), rd->cam, sizeof(cam_info));
+}
 
 static u64 now_us(void)
 {
@@ -203,6 +210,13 @@ void ray_dispatcher_run_jobs(ray_dispatcher* rd)
     crt_range todo[CRT_MAX_RANGES];
     const int n_todo = crt_ranges_complement(be->resume ? be->resume->ranges : NULL, be->resume ? be->resume->n_ranges : 0,
                                              rd->spp, todo, CRT_MAX_RANGES);
+    if (n_todo < 0) {
+        /* more gaps than the range table holds: rendering nothing and writing an image would be a silent lie */
+        fprintf(stderr, "ray_dispatcher_run_jobs: the resumed frame's missing samples do not fit %d ranges\n", CRT_MAX_RANGES);
+        rd->status = CASTER_HIP_ERR_ARG;
+        be->started = 0;
+        return;
+    }
     const long long total = n_todo > 0 ? crt_ranges_total(todo, n_todo) : 0;
     for (int g = 0; g < G; g++) {
         gpu_job* job = &be->jobs[g];
@@ -213,13 +227,62 @@ void ray_dispatcher_run_jobs(ray_dispatcher* rd)
         const i32 first = (i32)((total * g) / G);
         const i32 count = (i32)((total * (g + 1)) / G) - first;
         job->n_seg = n_todo > 0 ? crt_ranges_slice(todo, n_todo, first, count, job->seg, CRT_MAX_RANGES) : 0;
-        if (job->n_seg < 0) job->n_seg = 0;
+        if (job->n_seg < 0) {
+            fprintf(stderr, "ray_dispatcher_run_jobs: job %d's share of the samples does not fit %d ranges\n", g, CRT_MAX_RANGES);
+            job->n_seg = 0;
+            job->status = CASTER_HIP_ERR_ARG;
+            rd->status = CASTER_HIP_ERR_ARG;
+            continue;                                                 /* not launched */
+        }
         if (pthread_create(&be->threads[g], NULL, job_main, job) != 0) {
             job->status = CASTER_HIP_ERR_STATE;
             rd->status = CASTER_HIP_ERR_STATE;
+        } else {
+            job->thread_started = 1;
         }
         if (rd->last_id <= rd->thread_count) rd->last_id++;           /* src/dispatcher.c:111 */
     }
+}
+
+/* The sum of the jobs' radiance sums into job 0's buffer; they are linear and must be added before
+ * the scale and the gamma (src/dispatcher.c:29-30).  Jobs that share a GPU are added into the first
+ * job on that GPU with an add kernel; the per-GPU sums then meet in ONE RCCL reduce over the node's
+ * xGMI links (caster_hip_reduce), everything queued on the GPUs' streams without a host wait in
+ * between.  Without RCCL the per-GPU sums are added pairwise over the peer links instead -- a tree of
+ * log2(G) rounds whose adds run concurrently -- and a line on stderr says so. */
+static int sum_jobs(gpu_backend* be, size_t n_floats, const char** how)
+{
+    gpu_job* lead[MAX_THREADS];
+    int n_lead = 0, rc = 0;
+    *how = "one buffer";
+    for (int g = 0; g < be->n_jobs; g++) {
+        gpu_job* job = &be->jobs[g];
+        int l = 0;
+        while (l < n_lead && lead[l]->device != job->device) l++;
+        if (l == n_lead) { lead[n_lead++] = job; continue; }
+        *how = "add kernels";
+        if ((rc = caster_hip_add_from_device(lead[l]->ctx, lead[l]->accum_dev, job->device, job->accum_dev, n_floats))) return rc;
+    }
+    if (n_lead > 1) {
+        caster_hip_ctx* ctxs[MAX_THREADS];
+        float* bufs[MAX_THREADS];
+        for (int l = 0; l < n_lead; l++) { ctxs[l] = lead[l]->ctx; bufs[l] = lead[l]->accum_dev; }
+        *how = "RCCL reduce";
+        rc = caster_hip_reduce(ctxs, bufs, n_lead, n_floats);
+        if (rc) {
+            fprintf(stderr, "fence: %s; adding the %d GPUs' sums pairwise over the peer links instead\n", caster_hip_last_error(), n_lead);
+            *how = "pairwise peer adds";
+            rc = 0;
+            for (int stride = 1; stride < n_lead && !rc; stride *= 2) {
+                for (int l = 0; l < n_lead && !rc; l++) rc = caster_hip_synchronize(lead[l]->ctx);    /* sources complete */
+                for (int l = 0; l + stride < n_lead && !rc; l += 2 * stride)
+                    rc = caster_hip_add_from_device(lead[l]->ctx, lead[l]->accum_dev, lead[l + stride]->device,
+                                                    lead[l + stride]->accum_dev, n_floats);
+            }
+        }
+    }
+    if (!rc) rc = caster_hip_synchronize(be->jobs[0].ctx);
+    return rc;
 }
 
 clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
@@ -228,7 +291,7 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
     if (!be || !be->started) return clock();
     const size_t n_px = (size_t)rd->block_width * rd->block_height;
     for (int g = 0; g < be->n_jobs; g++) {
-        if (be->jobs[g].rd) pthread_join(be->threads[g], NULL);
+        if (be->jobs[g].thread_started) pthread_join(be->threads[g], NULL);
         if (be->jobs[g].status && !rd->status) rd->status = be->jobs[g].status;
     }
     /* the sample ranges the frame now holds */
@@ -245,13 +308,12 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
     if (!rd->status && be->n_jobs > 0) {
         gpu_job* root = &be->jobs[0];
         int done = root->samples_done + (be->resume ? crt_ranges_total(be->resume->ranges, be->resume->n_ranges) : 0);
-        /* radiance sums are linear: add them before the scale and the gamma (src/dispatcher.c:29-30).
-         * Job 0's GPU pulls the other GPUs' sums over the peer links, in job order. */
-        int rc = 0;
-        for (int g = 1; g < be->n_jobs && !rc; g++) {
-            rc = caster_hip_add_from_device(root->ctx, root->accum_dev, be->jobs[g].device, be->jobs[g].accum_dev, n_px * 4);
-            done += be->jobs[g].samples_done;
-        }
+        for (int g = 1; g < be->n_jobs; g++) done += be->jobs[g].samples_done;
+        const char* how = "";
+        const u64 t_sum = now_us();
+        int rc = sum_jobs(be, n_px * 4, &how);
+        rd->fence_sum_us = now_us() - t_sum;
+        rd->fence_sum_how = how;
         if (!rc && done > 0 && rd->image && rd->image->data)
             rc = caster_hip_resolve(root->ctx, root->accum_dev, rd->block_width, rd->block_height, done, rd->image->data);
         if (!rc && be->checkpoint_path) {
@@ -259,7 +321,7 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd)
             memset(&cp, 0, sizeof cp);
             cp.width = (u32)rd->block_width; cp.height = (u32)rd->block_height;
             cp.seed = be->seed; cp.strict = be->strict ? 1 : 0; cp.max_depth = rd->max_depth;
-            cp.scene_hash = crt_flat_hash(be->flat);
+            cp.scene_hash = frame_hash(be, rd);
             cp.n_ranges = n_held < CRT_MAX_RANGES ? n_held : CRT_MAX_RANGES;
             memcpy(cp.ranges, held, (size_t)cp.n_ranges * sizeof(crt_range));
             cp.sums = (f32*)malloc(n_px * 4 * sizeof(f32));
@@ -303,8 +365,8 @@ int ray_dispatcher_resume(ray_dispatcher* rd, const char* path)
     if (!cp) { fprintf(stderr, "resume: cannot read %s\n", path ? path : "(null)"); return -1; }
     if (cp->width != (u32)rd->block_width || cp->height != (u32)rd->block_height || cp->seed != be->seed ||
         (cp->strict != 0) != (be->strict != 0) || cp->max_depth != rd->max_depth ||
-        cp->scene_hash != crt_flat_hash(be->flat)) {
-        fprintf(stderr, "resume: %s belongs to another frame (size, seed, arithmetic mode, depth or scene differ)\n", path);
+        cp->scene_hash != frame_hash(be, rd)) {
+        fprintf(stderr, "resume: %s belongs to another frame (size, seed, arithmetic mode, depth, camera or scene differ)\n", path);
         crt_checkpoint_free(cp);
         return -1;
     }

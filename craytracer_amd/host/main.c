@@ -91,6 +91,9 @@ int main(int argc, char* argv[])
     ray_dispatcher_worker_fence(&dispatcher);                                 /* src/main.c:107 */
     clock_gettime(CLOCK_MONOTONIC, &t1);
     const int status = dispatcher.status;
+    if (dispatcher.thread_count > 1 && dispatcher.fence_sum_how)
+        printf("Fence: %d buffers summed in %.3f ms (%s)\n", (int)dispatcher.thread_count, dispatcher.fence_sum_us * 1e-3,
+               dispatcher.fence_sum_how);
     u64 rays = 0;
     for (int g = 0; g < dispatcher.thread_count; g++) rays += dispatcher.rays_total[g];
     free_ray_dispatcher(&dispatcher);

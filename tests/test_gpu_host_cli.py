@@ -90,3 +90,47 @@ def test_cli_checkpoint_and_resume_give_the_uninterrupted_frame(tmp_path, ca):
     bad = subprocess.run([exe, str(height), "12", str(depth), "1", "--scene", "rtiow", "--strict", "--seed", "32", "--resume", ck],
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode == 1 and "another frame" in bad.stderr
+
+
+def test_cli_resume_with_another_texture_is_refused(tmp_path, ca):
+    """The identity of a checkpoint covers the texture images (and the camera and noise tables), not
+    only the object and material tables: resuming scene 0 with another --texture must be refused."""
+    exe = os.path.join(os.path.dirname(ca.lib_paths()["host"]), "craytracer")
+    ck = str(tmp_path / "frame.ck")
+    tex_a, tex_b = str(tmp_path / "a.bmp"), str(tmp_path / "b.bmp")
+    img = ca.make_test_texture(64, 32)
+    rgba = np.zeros((32, 64, 4), np.uint8)
+    rgba[..., :3] = img
+    open(tex_a, "wb").write(ca.bmp_encode(rgba))
+    rgba[5, 7, 1] ^= 0x40                                     # one texel differs
+    open(tex_b, "wb").write(ca.bmp_encode(rgba))
+    base = [exe, "36", "4", "20", "1", "--scene", "0", "--strict", "--out", str(tmp_path / "o.bmp")]
+    p = subprocess.run(base + ["--texture", tex_a, "--checkpoint", ck], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    same = subprocess.run(base[:2] + ["8"] + base[3:] + ["--texture", tex_a, "--resume", ck], capture_output=True, text=True, timeout=120)
+    assert same.returncode == 0, same.stderr
+    other = subprocess.run(base[:2] + ["8"] + base[3:] + ["--texture", tex_b, "--resume", ck], capture_output=True, text=True, timeout=120)
+    assert other.returncode == 1 and "another frame" in other.stderr
+
+
+def test_cli_eight_jobs_report_the_fence_sum(tmp_path, ca):
+    """Eight jobs (the job count of an 8-GPU node) on the one GPU of the test box, at the headline frame
+    size with one GPU's share of samples each: the fence adds the eight 33 MB buffers and reports how
+    long that took and by which route (add kernels here; one RCCL reduce between distinct GPUs)."""
+    exe = os.path.join(os.path.dirname(ca.lib_paths()["host"]), "craytracer")
+    outs = {}
+    for jobs in (1, 8):
+        out = str(tmp_path / f"j{jobs}.bmp")
+        p = subprocess.run([exe, "1080", "8", "50", "1", "--scene", "rtiow", "--strict", "--jobs", str(jobs), "--out", out],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        outs[jobs] = (open(out, "rb").read(), p.stdout)
+    line = [ln for ln in outs[8][1].splitlines() if ln.startswith("Fence:")]
+    assert len(line) == 1 and "8 buffers summed in" in line[0] and "add kernels" in line[0]
+    ms = float(line[0].split("summed in ")[1].split(" ms")[0])
+    assert 0.0 < ms < 50.0
+    print(line[0])
+    a, b = _bmp_pixels(outs[1][0], 1920, 1080), _bmp_pixels(outs[8][0], 1920, 1080)
+    assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a == b).mean() > 0.999
+    rays = [int(outs[j][1].split("Rays: ")[1].split()[0]) for j in (1, 8)]
+    assert rays[0] == rays[1]
