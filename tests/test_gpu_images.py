@@ -241,14 +241,33 @@ def test_empty_and_degenerate_inputs(gpu, ca):
         gpu.upload_scene(ca.FlatScene(bad, fs.materials, []))
 
 
-def test_fast_mode_statistically_equal(gpu, orc, ca):
+@pytest.mark.parametrize("name", ["rtiow", "stress_500", "stress_4500", "offset"])
+def test_fast_mode_statistically_equal(gpu, orc, ca, name):
     """Fast arithmetic (FMA, reordered ops) renders the same image up to Monte-Carlo noise: at
     equal seeds almost every path is identical, so the images are far closer than the
-    PSNR > 45 dB / mean-abs-error < 1/255 bar set for images against unmodified CRaytracer."""
-    fs = ca.scene_rtiow(1)
-    gpu.upload_scene(fs)
+    PSNR > 45 dB / mean-abs-error < 1/255 bar set for images against unmodified CRaytracer.
+    Holds for scenes whose coordinates leave the reference's fixed tmin = 0.001 (src/caster.c:441)
+    well above the FP32 spacing of a hit point; where they do not (spheres hundreds of units across,
+    thousands of units from the origin), surface rays re-hit their own sphere or not depending on the
+    last bit, in the reference's arithmetic as in any other, and only the strict mode reproduces the
+    reference's outcome (tools/fast_drift.py shows +8 % and +11 % rays on two such scenes)."""
     w, h, spp, depth, seed = 96, 54, 64, 50, 1234
     cam = ca.default_camera(w / h)
+    if name == "rtiow":
+        fs = ca.scene_rtiow(1)
+    elif name == "stress_500":
+        fs = ca.scene_stress(500, 2)
+    elif name == "stress_4500":
+        fs = ca.scene_stress(4500, 2)
+        spp = 128
+    else:
+        fs = ca.scene_rtiow(5)
+        objs = fs.objects.copy()
+        objs["g"][:, 0] += 3000.0
+        objs["g"][:, 2] -= 1500.0
+        fs = ca.FlatScene(objs, fs.materials, [])
+        cam = ca.calculate_cam_info((3013, 2, -1497), (3000, 0, -1500), (0, 1, 0), 20.0, np.float32(w / h), 0.1, 10.0)
+    gpu.upload_scene(fs)
     s, rs, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
     f, rf, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=False)
     a = np.sqrt(np.clip(s[..., :3] / spp, 0, None)).clip(0, 1)
@@ -258,7 +277,7 @@ def test_fast_mode_statistically_equal(gpu, orc, ca):
     # Ray counts differ by well under 2 %: the two modes part on grazing rays trapped inside
     # glass spheres, where the sign of a discriminant near zero depends on the rounding.
     assert abs(rs - rf) / rs < 2e-2
-    assert mae < 1 / 255 and psnr > 45, (mae, psnr)
+    assert mae < 1 / 255 and psnr > 45, (name, mae * 255, psnr)
 
 
 def test_full_size_frame_properties(gpu, orc, ca):
