@@ -44,11 +44,11 @@ constexpr int kCounterWords = 4;
 
 // Scratch of caster_hip_render_noalloc: the counters and the per-pixel fixed-point sums of a call,
 // which caster_hip_render keeps in buffers it allocates.  A file-scope device array: every GPU the
-// library runs on holds its own copy (32 MiB + 32 B) at its own address until the process ends.  In
+// library runs on holds its own copy (24 MiB + 32 B) at its own address until the process ends.  In
 // host code the name is only a handle for hipGetSymbolAddress (caster_hip_create asks once per
 // device and keeps the pointer); kernels and hipMemsetAsync are given that pointer, never the name.
 constexpr size_t kNoAllocMaxPixels = (size_t)CASTER_HIP_NOALLOC_MAX_PIXELS;
-static __device__ __align__(256) unsigned long long scratch[kCounterWords + 4 * kNoAllocMaxPixels];
+static __device__ __align__(256) unsigned long long scratch[kCounterWords + 3 * kNoAllocMaxPixels];
 
 namespace {
 constexpr int kMaxDevices = 64;
@@ -559,7 +559,7 @@ static int plan_chunks(const caster_hip_ctx* ctx, int width, int height, int sam
     return n;
 }
 
-// The body of both render entry points.  `fixed` (width * height * 4 words) and `counters`
+// The body of both render entry points.  `fixed` (three planes of width * height words) and `counters`
 // (kCounterWords words) are the call's scratch: the context's own buffers, or this device's copy of
 // the static array.  Nothing here allocates.
 static int render_on(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height, int sample_begin,
@@ -578,7 +578,7 @@ static int render_on(caster_hip_ctx* ctx, const caster_camera* cam, int width, i
         return CASTER_HIP_OK;
     }
     const size_t n_pixels = (size_t)width * height;
-    HIP_TRY(hipMemsetAsync(fixed, 0, n_pixels * 4 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(fixed, 0, n_pixels * 3 * sizeof(unsigned long long), ctx->stream));
 
     caster::RenderArgs a;
     a.cam = cam_rec(cam);
@@ -629,7 +629,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
     int rc = check_render_args(ctx, cam, width, height, sample_begin, sample_count, flags, accum_dev);
     if (rc) return rc;
     DeviceGuard guard(ctx->device);
-    const size_t need = (size_t)width * height * 4 * sizeof(unsigned long long);
+    const size_t need = (size_t)width * height * 3 * sizeof(unsigned long long);
     if (sample_count > 0 && need > ctx->fixed_bytes) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->fixed) HIP_TRY(hipFree(ctx->fixed));

@@ -75,7 +75,7 @@ struct RenderArgs {
     int chunk_start[kMaxChunks + 1];   // chunk c covers samples s_begin + [chunk_start[c], chunk_start[c+1])
     int max_depth;
     uint32_t seed;
-    unsigned long long* fixed; // width * height * 4 fixed-point sums (2^-32 units), zero at launch
+    unsigned long long* fixed; // three planes (R, G, B) of width * height fixed-point sums (2^-32 units), zero at launch
     unsigned long long* rays;
     unsigned int* queue;     // work-unit queue head, zero at launch
     unsigned long long* trips; // wave trips through the sphere loop (128 ray slots each), zero at launch

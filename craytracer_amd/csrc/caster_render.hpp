@@ -25,8 +25,8 @@
 //     a pixel's sum does not depend on the order in which paths end, on the
 //     route their radiance takes or on the unit-to-wave assignment, and a
 //     render is bit-reproducible;
-//   * the frame buffer is a per-pixel fixed-point buffer in HBM (64-bit
-//     integer atomics); a later kernel converts it to float once.
+//   * the frame buffer is a fixed-point buffer in HBM, one plane per channel
+//     (64-bit integer atomics); a later kernel converts it to float once.
 //
 // Every ray is tested against every sphere (src/caster.c:204 has no early
 // out): the loop evaluates a conservative candidate test, notes the few
@@ -211,17 +211,20 @@ CDEV void refill(Slot& s, Unit& un, const RenderArgs& a, const Cam& cam, const P
     un.next += __popcll(want);
 }
 
-// Adds the sums of a unit's tile to the frame's fixed-point buffer (4 words per pixel: R, G, B,
-// unused) and clears the accumulator.
+// Adds the sums of a unit's tile to the frame's fixed-point buffer and clears the accumulator.  The
+// buffer is three planes (R, G, B) of one word per pixel: the eight lanes of a tile row then add to
+// eight consecutive words, 64 bytes, which leave the L2 as one atomic request (with the channels
+// interleaved per pixel every lane's atomic was a 64-byte request of its own: 8 x the traffic).
 CDEV void flush_unit(const Unit& un, acc_t* acc_set, const RenderArgs& a, int lane)
 {
     const int qx = lane & 7, qy = lane >> 3;
     if (qx < un.tg.tw && qy < un.tg.th) {
-        acc_t* px = a.fixed + 4 * ((size_t)(un.tg.y0 + qy) * a.width + (un.tg.x0 + qx));
+        const size_t plane = (size_t)a.width * (size_t)a.height;
+        acc_t* px = a.fixed + ((size_t)(un.tg.y0 + qy) * a.width + (un.tg.x0 + qx));
         const acc_t r = acc_set[lane * 3 + 0], g = acc_set[lane * 3 + 1], b = acc_set[lane * 3 + 2];
-        if (r) atomicAdd(px + 0, r);
-        if (g) atomicAdd(px + 1, g);
-        if (b) atomicAdd(px + 2, b);
+        if (r) atomicAdd(px, r);
+        if (g) atomicAdd(px + plane, g);
+        if (b) atomicAdd(px + 2 * plane, b);
     }
     acc_set[lane * 3 + 0] = 0; acc_set[lane * 3 + 1] = 0; acc_set[lane * 3 + 2] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -909,10 +912,11 @@ CDEV void deposit(int q, V3 radiance, const TileGeom& tg, acc_t* wave_acc, const
         if (fg) atomicAdd(px + 1, fg);
         if (fb) atomicAdd(px + 2, fb);
     } else {
-        acc_t* px = a.fixed + 4 * ((size_t)j * a.width + i);
-        if (fr) atomicAdd(px + 0, fr);
-        if (fg) atomicAdd(px + 1, fg);
-        if (fb) atomicAdd(px + 2, fb);
+        const size_t plane = (size_t)a.width * (size_t)a.height;
+        acc_t* px = a.fixed + ((size_t)j * a.width + i);
+        if (fr) atomicAdd(px, fr);
+        if (fg) atomicAdd(px + plane, fg);
+        if (fb) atomicAdd(px + 2 * plane, fb);
     }
 }
 

@@ -12,12 +12,12 @@ __global__ void k_fold(const unsigned long long* fixed, int n_pixels, int sample
 {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pixels) return;
-    const ulonglong4 f = reinterpret_cast<const ulonglong4*>(fixed)[p];
+    const unsigned long long fr = fixed[p], fg = fixed[(size_t)n_pixels + p], fb = fixed[2 * (size_t)n_pixels + p];   // planes R, G, B
     const double k = 1.0 / 4294967296.0;
     float4 acc = accum[p];
-    acc.x = acc.x + (float)((double)f.x * k);
-    acc.y = acc.y + (float)((double)f.y * k);
-    acc.z = acc.z + (float)((double)f.z * k);
+    acc.x = acc.x + (float)((double)fr * k);
+    acc.y = acc.y + (float)((double)fg * k);
+    acc.z = acc.z + (float)((double)fb * k);
     acc.w = acc.w + (float)sample_count;
     accum[p] = acc;
 }

@@ -171,8 +171,8 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
  * Same arguments, same result bit for bit, same asynchrony; it calls no hipMalloc/hipFree or any
  * other allocating routine: the scratch that caster_hip_render keeps in buffers it allocates on
  * first use (the per-pixel fixed-point sums of the call, the ray and trip counters, the work
- * queue's head) lives in a static device array of CASTER_HIP_NOALLOC_MAX_PIXELS * 32 + 32 bytes
- * (32 MiB) that every GPU the library runs on holds until the process ends.  Frames of more pixels
+ * queue's head) lives in a static device array of CASTER_HIP_NOALLOC_MAX_PIXELS * 24 + 32 bytes
+ * (24 MiB) that every GPU the library runs on holds until the process ends.  Frames of more pixels
  * are refused with CASTER_HIP_ERR_ARG.  All contexts on one GPU share that GPU's array: calls that
  * overlap on one GPU (two streams, two contexts, two threads) race; calls in stream order do not,
  * each clears what it needs.  caster_hip_render_stats / _info afterwards report this call. */

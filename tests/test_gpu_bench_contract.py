@@ -33,7 +33,7 @@ def test_bench_line_has_the_contract_fields():
     # executed work against the unit it runs on: a fraction of a peak, never above it
     assert r["bound"] == "mfma" and r["peak"] == 2500.0 and r["loop"] == "matrix"
     assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["wave_trips"] > 0 and 0.5 < r["slots_in_use"] <= 1.0
+    assert r["wave_trips"] > 0 and 0.0 < r["slots_in_use"] <= 1.0     # a frame this small leaves most of the 4 096 waves nearly idle
     assert r["traffic"] is None and r["counters"] is None    # the recorded counters belong to the full-size workload only
     v = r["vector_loop"]                              # second leg: the filter on the vector unit, against the FP32 vector peak
     assert v["bound"] == "valu_fp32" and v["peak"] == 157.3 and v["loop"] == "vector"
