@@ -87,7 +87,9 @@ def main():
                 json.dump({"workload": workload, "arithmetic_mode": mode, "kernel": names, "FETCH_SIZE_KB": c["FETCH_SIZE"],
                            "WRITE_SIZE_KB": c["WRITE_SIZE"], "bytes_per_launch": fig["hbm_bytes_per_launch"],
                            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc.sh), one launch each, summed "
-                                  "over XCDs; bytes = 2 x FETCH_SIZE x 1024 (gfx950 reports half of wide reads) + WRITE_SIZE x 1024"}, f, indent=1)
+                                  "over XCDs; bytes = 2 x FETCH_SIZE x 1024 (gfx950 reports half of wide reads) + WRITE_SIZE x 1024; the writes are "
+                                  "64-bit integer atomics, which WRITE_SIZE tallies as 8 bytes each when a wave's lanes add to consecutive words "
+                                  "and as a 32-byte request otherwise (tools/atomic_traffic.hip)"}, f, indent=1)
     with open(prefix + "_pmc_summary.json", "w") as f:
         json.dump({"how": "rocprofv3 --pmc, separate passes (tools/pmc.sh), one launch of the render kernel per pass; "
                           "figures derived by tools/pmc_summary.py", "kernels": kernels}, f, indent=1)
