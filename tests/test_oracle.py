@@ -269,3 +269,76 @@ def test_noise_properties(orc, ca, vectors):
     t_scene = orc.noise_turb(fs.noise, p[:100])
     want = 0.5 * (1 + np.sin(fs.materials["color1"][m, 0].astype(np.float64) * p[:100, 2] + 10.0 * t_scene.astype(np.float64)))
     assert np.allclose(rgb, fs.materials["color0"][m][None, :] * want[:, None], atol=1e-5)
+
+
+def test_math_functions_closed_forms(orc):
+    """The small optics functions of the restatement against what their definitions say in float64
+    (src/common.c:152-175, src/material.c:45-56): Schlick's polynomial, Snell's law, mirror reflection,
+    the spherical uv map with its poles and seam, the near-zero threshold."""
+    rng = np.random.default_rng(31)
+    n = 4000
+
+    def in8(*cols):
+        a = np.zeros((len(cols[0]), 8), np.float32)
+        k = 0
+        for c in cols:
+            c = np.asarray(c, np.float32).reshape(len(cols[0]), -1)
+            a[:, k:k + c.shape[1]] = c
+            k += c.shape[1]
+        return a
+
+    cos = rng.uniform(0, 1, n).astype(np.float32)
+    ratio = rng.choice(np.array([1.5, 1 / 1.5, 1.33], np.float32), n)
+    got = orc.math(orc.MATH_REFLECTANCE, in8(cos, ratio))[:, 0]
+    r0 = ((1 - ratio.astype(np.float64)) / (1 + ratio)) ** 2
+    assert np.allclose(got, r0 + (1 - r0) * (1 - cos.astype(np.float64)) ** 5, rtol=2e-6, atol=1e-7)
+    assert orc.math(orc.MATH_REFLECTANCE, in8([1.0], [1.5]))[0, 0] == np.float32(np.float32(np.float32(-0.5) / np.float32(2.5)) ** 2)
+
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[(d * nrm).sum(1) > 0] *= -1
+    refl = orc.math(orc.MATH_REFLECT, in8(d, nrm))
+    assert np.allclose(refl, d - 2 * (d * nrm).sum(1, keepdims=True) * nrm, atol=2e-6)
+    assert np.allclose(np.linalg.norm(refl, axis=1), 1.0, atol=2e-6)
+    # refraction into the denser medium (ratio 1/1.5): Snell's law sin(t) = ratio * sin(i), unit length
+    cos_i = np.minimum((-d * nrm).sum(1), 1.0)
+    refr = orc.math(orc.MATH_REFRACT, in8(d, nrm, np.full(n, 1 / 1.5), cos_i)).astype(np.float64)
+    assert np.allclose(np.linalg.norm(refr, axis=1), 1.0, atol=1e-5)
+    sin_i = np.sqrt(np.maximum(0, 1 - cos_i ** 2))
+    sin_t = np.linalg.norm(np.cross(refr, nrm), axis=1)
+    assert np.allclose(sin_t, sin_i / 1.5, atol=1e-5)
+
+    uv = orc.math(orc.MATH_UV_SPHERE, in8(nrm))[:, :2].astype(np.float64)
+    assert np.allclose(uv[:, 0], (np.arctan2(-nrm[:, 2], nrm[:, 0]) + np.pi) / (2 * np.pi), atol=1e-6)
+    assert np.allclose(uv[:, 1], np.arccos(np.clip(-nrm[:, 1], -1, 1)) / np.pi, atol=1e-6)
+    poles = orc.math(orc.MATH_UV_SPHERE, in8(np.array([[0, 1, 0], [0, -1, 0], [-1, 0, 0.0], [-1, 0, -0.0]], np.float32)))
+    assert abs(poles[0, 1] - 1.0) < 1e-6 and poles[1, 1] == 0.0           # v: 1 at the north pole, 0 at the south
+    assert abs(poles[2, 0]) < 1e-6 and abs(poles[3, 0] - 1.0) < 1e-6       # the seam: atan2(-z, x) is -pi for z = +0, +pi for z = -0
+
+    s = np.float32(1e-8)
+    v = np.array([[0, 0, 0], [9e-9, -9e-9, 9e-9], [1e-8, 0, 0], [0, 2e-8, 0], [9e-9, 9e-9, 1e-7]], np.float32)
+    assert list(orc.math(orc.MATH_NEAR_ZERO, in8(v))[:, 0]) == [1.0, 1.0, 0.0, 0.0, 0.0]
+    assert (np.abs(v[2, 0]) < s) == False                                  # 1e-8f is not below itself
+    u = orc.math(orc.MATH_TO_UNIT, in8(rng.normal(size=(n, 3)) * 37.0))
+    assert np.allclose(np.linalg.norm(u.astype(np.float64), axis=1), 1.0, atol=3e-7)
+
+
+def test_counter_rng_render_agrees_with_the_libc_rand_golden(orc, ca):
+    """The restatement on its counter generator against the committed high-spp render on libc rand()
+    (tests/golden/libc_images.npz): two independent estimates of one expectation.  Their difference
+    must be noise of the size the sample counts predict (no bias), which is what lets the GPU path,
+    on the counter generator, be compared with renders on the reference's random source."""
+    import os
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "libc_images.npz"))
+    w, h, spp_ref, depth = (int(x) for x in gold["rtiow_cfg"])
+    ref = np.sqrt(np.clip(gold["rtiow_mean"], 0, None)).clip(0, 0.999)
+    spp = 24
+    sums, _, rays = orc.dispatch(orc.Scene.from_flat(ca.scene_rtiow(1)), ca.default_camera(w / h), w, h, spp, depth, 77, 8)
+    img = np.sqrt(np.clip(sums[..., :3] / spp, 0, None)).clip(0, 0.999)
+    diff = img.astype(np.float64) - ref
+    psnr = 10 * np.log10(1.0 / np.mean(diff ** 2))
+    # per-sample variance in display space is 0.020 on this frame: 24 spp against 2048 predicts ~31 dB
+    assert 28.0 < psnr < 36.0, psnr
+    assert abs(diff.mean()) < 1.5 / 255, diff.mean()                      # sqrt of a noisy mean is biased low by ~var/(8 m^1.5)
+    assert abs(rays / (w * h * spp) - float(gold["rtiow_rays"]) / (w * h * spp_ref)) < 0.03
