@@ -29,6 +29,8 @@ ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--modes", default="fast,strict")
 ap.add_argument("--vector-loop", action="store_true", help="sphere filter on the vector unit (CASTER_HIP_VECTOR_LOOP)")
+ap.add_argument("--order", default="list", choices=["list", "morton", "random"],
+                help="experiment: reorder the scene's object list (changes which of two equal hits wins, nothing else)")
 args = ap.parse_args()
 
 if args.scene == "rtiow":
@@ -41,6 +43,25 @@ elif args.scene.startswith("stress:"):
     fs = ca.scene_stress(int(args.scene.split(":")[1]), 2)
 else:
     raise SystemExit("unknown scene")
+if args.order != "list":
+    g = fs.objects["g"]
+    if args.order == "random":
+        perm = np.random.default_rng(1).permutation(len(fs.objects))
+    else:
+        small = g[:, 3] < 50
+        lo, hi = g[small, :3].min(axis=0), g[small, :3].max(axis=0)
+        q = np.clip((g[:, :3] - lo) / np.maximum(hi - lo, 1e-9) * 1023, 0, 1023).astype(np.uint64)
+
+        def spread(v):      # 10 bits -> every third bit
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+
+        code = spread(q[:, 0]) | (spread(q[:, 2]) << 1) | (spread(q[:, 1]) << 2)
+        code[~small] = np.uint64(1) << 40          # the huge spheres last
+        perm = np.argsort(code, kind="stable")
+    fs = ca.FlatScene(fs.objects[perm].copy(), fs.materials, fs.images, fs.noise)
 ns, nr = fs.n_spheres, fs.n_rects
 gpu = ca.CasterHip(0)
 gpu.upload_scene(fs)
