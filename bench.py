@@ -107,11 +107,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    # Rehearsal switches for a one-GPU box (tests only): all ranks on device 0 and a backend that accepts
+    # several ranks per GPU.  A real run has one rank per GPU over RCCL.
+    backend = os.environ.get("CASTER_BENCH_BACKEND", "nccl")
+    if os.environ.get("CASTER_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     W, H, SPP = args.width, args.height, args.spp
     fs = ca.scene_rtiow(1)
@@ -223,7 +231,8 @@ def main():
                 "workload": workload,
                 "objects": int(len(fs.objects)),
                 "arithmetic_mode": args.mode,
-                "parallelism": f"sample-partition x{world}" + (" + RCCL sum-reduce to rank 0" if world > 1 else ""),
+                "parallelism": f"sample-partition x{world}" + ((" + RCCL sum-reduce to rank 0" if backend == "nccl" else
+                                                                f" + {backend} sum-reduce to rank 0 (rehearsal)") if world > 1 else ""),
                 "seed": args.seed,
             },
             "ms_per_frame": round(ms_per_step, 3),
