@@ -144,18 +144,35 @@ def main():
     rays_step = [0]
     info_step = [None]
 
+    trace = os.environ.get("CASTER_BENCH_TRACE") == "1"
+
+    def note(what):
+        if trace:
+            print(f"[rank {rank}] {what}", file=sys.stderr, flush=True)
+
+    def reduce_sum():
+        if backend == "nccl":
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)          # RCCL, on the stream the library renders on
+        else:                                                        # rehearsal: the sum through host memory
+            host = accum.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            accum.copy_(host)
+
     def one_step(vector_loop=False):
         # everything of a frame is queued on one stream without a host wait in between: clear, render,
         # sum over ranks (RCCL), resolve; the host then waits once for the frame
+        note("step: clear")
         accum.zero_()
         begin, count = render_frame(
             lambda b, c: gpu.render(cam, W, H, b, c, args.depth, args.seed, accum.data_ptr(), strict=strict,
                                     vector_loop=vector_loop),
-            (lambda: dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)) if world > 1 else None,
+            reduce_sum if world > 1 else None,
             SPP, world, rank)
+        note("step: rendered and reduced (queued)")
         if rank == 0:
             gpu.resolve_dev(accum.data_ptr(), W, H, SPP, rgba.data_ptr())
         info = gpu.render_info()               # waits for this rank's frame: the frame boundary
+        note("step: frame complete")
         rays_step[0] = info["rays"]
         info_step[0] = info
         kernel_ms.append(info["kernel_ms"])    # HIP events on the kernel's own stream, around the kernel alone
@@ -187,9 +204,10 @@ def main():
         vector_leg = (info_step[0], float(np.mean(kernel_ms)), tv / args.vector_steps * 1e3)
         rays_step[0] = main_info["rays"]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    r = torch.tensor([float(rays_step[0])], dtype=torch.float64, device=dev)
-    k = torch.tensor([main_kernel_ms], dtype=torch.float64, device=dev)
+    stat_dev = dev if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
+    r = torch.tensor([float(rays_step[0])], dtype=torch.float64, device=stat_dev)
+    k = torch.tensor([main_kernel_ms], dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
