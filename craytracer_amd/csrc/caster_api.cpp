@@ -443,8 +443,11 @@ int caster_hip_upload_scene(caster_hip_ctx* ctx, int n_objects, const caster_obj
     s.n_mat = n_materials;
     s.n_img = n_images;
     ctx->has_scene = true;
-    for (int k = 0; k < n_materials; ++k)
+    s.all_solid = 1;
+    for (int k = 0; k < n_materials; ++k) {
         if (materials[k].tex_type == CASTER_TTYPE_NOISE) ctx->needs_noise = true;
+        if (materials[k].tex_type != CASTER_TTYPE_COLOR) s.all_solid = 0;
+    }
     return CASTER_HIP_OK;
 }
 

@@ -563,6 +563,9 @@ CDEV Ray ray_from_cam(const Cam& ci, Rng& g, float u, float v)  // camera.c:32-4
 // unrolled from recursion: returns true when the path continues along `next`
 // with its throughput multiplied by `atten`; false when the path ends with
 // radiance `emit` (black for a failed scatter or an unknown tag).
+// TEX false: for scenes whose every texture is a solid colour (TTYPE_COLOR), the instance leaves out
+// the checker, image and noise lookups altogether -- same values, a smaller kernel.
+template <bool TEX = true>
 CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& next, V3& atten, V3& emit)
 {
     const Mat m = sc.mats[rec.m];
@@ -611,7 +614,7 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
         break;
     }
     if (textured) {
-        const V3 c = texture_color(sc, m, rec);
+        const V3 c = TEX ? texture_color(sc, m, rec) : mk(m.c0[0], m.c0[1], m.c0[2]);
         if (m.type == 3) emit = c;
         else atten = c;
     }

@@ -45,6 +45,7 @@ struct SceneDev {
     const uint4* mfma_tab[2];// matrix-core filter operands (fast, strict): [block][2][64 lanes] x 8 halves, or null
     int mfma_blocks;         // blocks of 32 spheres in mfma_tab; 0: the scene does not qualify
     float mfma_scale;        // power of two that brings the scene into half-precision range
+    int all_solid;           // every material's texture is a solid colour (TTYPE_COLOR): the kernel may leave the texture code out
     int n_always;            // spheres tested directly for every ray, outside the filter
     int always[kMaxAlways];  // their indices
 };

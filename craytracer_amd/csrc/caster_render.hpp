@@ -922,6 +922,7 @@ CDEV void deposit(int q, V3 radiance, const TileGeom& tg, acc_t* wave_acc, const
 
 // One bounce of a slot's path: shade the hit and either continue the path or
 // end it (adding its radiance to the frame).
+template <bool TEX>
 CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, const TileGeom& tg, acc_t* wave_acc,
                  const RenderArgs& a, unsigned int& rays)
 {
@@ -937,7 +938,7 @@ CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, cons
     if (resolve_hit(s, r, closest, best_sph, sc, rec)) {
         Ray next;
         V3 atten, emit;
-        cont = shade(sc, s.g, r, rec, next, atten, emit);
+        cont = shade<TEX>(sc, s.g, r, rec, next, atten, emit);
         if (cont) {
             s.thr = s.thr * atten;
             set_ray(s, next);
@@ -975,7 +976,7 @@ constexpr int lds_fixed_bytes(int kind)
            kWaves * (kind >= kLoopMatrix ? kMfmaQueueBytes : 2 * kListCap * 64);
 }
 
-template <int KIND>
+template <int KIND, bool TEX>
 __global__ __launch_bounds__(kBlock, KIND >= kLoopMatrix ? CASTER_MATRIX_BLOCKS_PER_CU : CASTER_BLOCKS_PER_CU)
 void CASTER_NAME(render_kernel_)(RenderArgs a)
 {
@@ -1057,7 +1058,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const unsigned long long t_bounce = tm.now();
-            bounce(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
+            bounce<TEX>(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
             tm.add(WaveTimers::kBounce, t_bounce);
             const unsigned long long t_sched = tm.now();
             if (cur.chunk >= 0 && cur.next >= cur.total) {
@@ -1170,12 +1171,22 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     if (kind >= kLoopMatrix) resident_blocks = resident_blocks / CASTER_BLOCKS_PER_CU * CASTER_MATRIX_BLOCKS_PER_CU;
     if (blocks > resident_blocks) blocks = resident_blocks;      // persistent: the waves loop over the queue
     const dim3 grid((unsigned)blocks), block(kBlock);
+    // A scene whose every texture is a solid colour runs instances without the texture code (the
+    // benchmark's case).  The choice depends on the scene alone, never on the loop: the two loops of a
+    // scene must run the same shading code to give the same bits in the fast mode, where the
+    // compiler's choice of fused operations may differ between instances.
+#define CASTER_LAUNCH_KIND(K)                                                                                            \
+    do {                                                                                                                 \
+        if (a.scene.all_solid) hipLaunchKernelGGL((CASTER_NAME(render_kernel_)<K, false>), grid, block, lds_bytes, st, a); \
+        else hipLaunchKernelGGL((CASTER_NAME(render_kernel_)<K, true>), grid, block, lds_bytes, st, a);                   \
+    } while (0)
     switch (kind) {
-    case kLoopMatrix: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopMatrix>, grid, block, lds_bytes, st, a); break;
-    case kLoopMatrixLarge: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopMatrixLarge>, grid, block, lds_bytes, st, a); break;
-    case kLoopVectorTiled: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopVectorTiled>, grid, block, lds_bytes, st, a); break;
-    default: hipLaunchKernelGGL(CASTER_NAME(render_kernel_)<kLoopVector>, grid, block, lds_bytes, st, a); break;
+    case kLoopMatrix: CASTER_LAUNCH_KIND(kLoopMatrix); break;
+    case kLoopMatrixLarge: CASTER_LAUNCH_KIND(kLoopMatrixLarge); break;
+    case kLoopVectorTiled: CASTER_LAUNCH_KIND(kLoopVectorTiled); break;
+    default: CASTER_LAUNCH_KIND(kLoopVector); break;
     }
+#undef CASTER_LAUNCH_KIND
     return hipGetLastError();
 }
 
