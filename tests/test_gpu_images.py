@@ -301,3 +301,24 @@ def test_full_size_frame_properties(gpu, orc, ca):
     for j0 in (0, 430, 1078):
         o, _ = orc.render(sc, cam, w, h, spp, depth, seed, rows=(j0, j0 + 2))
         _assert_image_close(m[j0:j0 + 2], o[j0:j0 + 2], spp)
+
+
+def test_degenerate_frame_sizes_and_depths(gpu, orc, ca):
+    """Frames one pixel wide or high divide the pixel coordinate by zero exactly as the reference does
+    (src/dispatcher.c:21-22: (i + rnd) / (width - 1)): infinite or NaN image-plane coordinates, rays with
+    non-finite components, which pass every range test (src/caster.c:107,114).  Together with depth
+    limits of 1 and 2 (ray_color at depth 0 is black and uncounted, src/caster.c:436): ray counts equal,
+    sums equal to the image bar, NaN for NaN."""
+    for fs in (ca.scene_0(), ca.scene_rtiow(1)):
+        gpu.upload_scene(fs)
+        sc = orc.Scene.from_flat(fs)
+        for (w, h) in ((1, 7), (5, 1), (1, 1), (2, 2), (3, 1)):
+            cam = ca.default_camera(w / h)
+            for depth in (1, 2, 50):
+                g, g_rays, _ = gpu.render_image(cam, w, h, 6, depth, 5, strict=True)
+                o, o_rays = orc.render(sc, cam, w, h, 6, depth, 5)
+                assert g_rays == o_rays, (w, h, depth)
+                assert np.array_equal(np.isnan(g), np.isnan(o))
+                assert np.allclose(g, o, rtol=REL_TOL, atol=1e-7, equal_nan=True), (w, h, depth)
+                f, f_rays, _ = gpu.render_image(cam, w, h, 6, depth, 5, strict=False)
+                assert abs(f_rays - o_rays) <= max(2, o_rays // 10)
