@@ -353,6 +353,12 @@ class CasterHip:
     def synchronize(self):
         _check(self._lib.caster_hip_synchronize(self._ctx), "caster_hip_synchronize")
 
+    def mem_info(self):
+        """(free bytes, total bytes) of the context's GPU."""
+        free, total = C.c_size_t(), C.c_size_t()
+        _check(self._lib.caster_hip_mem_info(self._ctx, C.byref(free), C.byref(total)), "caster_hip_mem_info")
+        return free.value, total.value
+
     def add_from_device(self, dst_ptr: int, src_device: int, src_ptr: int, n_floats: int):
         """dst += src where src lives on another context's device (its work must be complete)."""
         _check(

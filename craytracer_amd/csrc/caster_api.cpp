@@ -522,6 +522,17 @@ int caster_hip_synchronize(caster_hip_ctx* ctx)
     return CASTER_HIP_OK;
 }
 
+int caster_hip_mem_info(caster_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes)
+{
+    if (!ctx) return fail(CASTER_HIP_ERR_ARG, "ctx is NULL");
+    DeviceGuard guard(ctx->device);
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return CASTER_HIP_OK;
+}
+
 // Splits the sample range of a call into the chunks of the work units (unit = 8x8 pixel tile x chunk;
 // the queue hands the units out chunk by chunk).  A unit's sums are collected in LDS and reach the
 // frame buffer with one atomic per pixel and channel; paths that outlive their unit pay three
@@ -1018,6 +1029,7 @@ struct Rccl {
     void* handle = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -1041,6 +1053,7 @@ int rccl_open()
     if (!g_rccl.field) return fail(CASTER_HIP_ERR_DEVICE, "RCCL symbol %s not found", name)
     RCCL_SYM(CommInitAll, "ncclCommInitAll");
     RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(CommAbort, "ncclCommAbort");
     RCCL_SYM(Reduce, "ncclReduce");
     RCCL_SYM(GroupStart, "ncclGroupStart");
     RCCL_SYM(GroupEnd, "ncclGroupEnd");
@@ -1077,6 +1090,16 @@ extern "C" int caster_hip_reduce(caster_hip_ctx* const* ctxs, float* const* accu
     if (rc) return rc;
     int prev = -1;
     (void)hipGetDevice(&prev);
+    // Everything that can fail without RCCL's doing is checked before the group is opened: a group
+    // that has taken some ranks' calls and not the others' must never be launched (the ranks that
+    // were launched would wait for the missing ones for ever, on streams the caller then waits on).
+    for (int k = 0; k < n; ++k) {
+        if (hipSetDevice(devices[(size_t)k]) != hipSuccess) {
+            if (prev >= 0) (void)hipSetDevice(prev);
+            return fail(CASTER_HIP_ERR_DEVICE, "hipSetDevice(%d) failed", devices[(size_t)k]);
+        }
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
     if (g_rccl.devices != devices) {
         for (ncclComm_t c : g_rccl.comms) (void)g_rccl.CommDestroy(c);
         g_rccl.comms.assign((size_t)n, nullptr);
@@ -1084,24 +1107,43 @@ extern "C" int caster_hip_reduce(caster_hip_ctx* const* ctxs, float* const* accu
         RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms.data(), n, devices.data()));
         g_rccl.devices = devices;
     }
+    // If a call of the group fails all the same, nothing of it is launched: the communicators are
+    // ended first (their queued work is cancelled with them), the group is closed only to leave
+    // RCCL's thread state clean, and the cache is dropped so that the next call makes new ones.
+    auto give_up = [&]() {
+        for (ncclComm_t c : g_rccl.comms)
+            if (c) (void)g_rccl.CommAbort(c);
+        (void)g_rccl.GroupEnd();
+        g_rccl.comms.clear();
+        g_rccl.devices.clear();
+        if (prev >= 0) (void)hipSetDevice(prev);
+    };
     // one rank per GPU, all driven from this thread: the calls of a group are issued together
     RCCL_TRY(g_rccl.GroupStart());
     for (int k = 0; k < n; ++k) {
         if (hipSetDevice(devices[(size_t)k]) != hipSuccess) {
-            (void)g_rccl.GroupEnd();
-            if (prev >= 0) (void)hipSetDevice(prev);
-            return fail(CASTER_HIP_ERR_DEVICE, "hipSetDevice(%d) failed", devices[(size_t)k]);
+            give_up();
+            return fail(CASTER_HIP_ERR_DEVICE, "hipSetDevice(%d) failed inside the group; the communicators were ended, nothing was launched",
+                        devices[(size_t)k]);
         }
         const ncclResult_t r = g_rccl.Reduce(accum_dev[k], accum_dev[k], n_floats, ncclFloat32, ncclSum, 0,
                                              g_rccl.comms[(size_t)k], ctxs[k]->stream);
         if (r != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            if (prev >= 0) (void)hipSetDevice(prev);
-            return fail(CASTER_HIP_ERR_DEVICE, "ncclReduce on device %d failed: %s", devices[(size_t)k], g_rccl.GetErrorString(r));
+            const char* why = g_rccl.GetErrorString(r);
+            give_up();
+            return fail(CASTER_HIP_ERR_DEVICE, "ncclReduce on device %d failed: %s; the communicators were ended, nothing was launched",
+                        devices[(size_t)k], why);
         }
     }
     const ncclResult_t r = g_rccl.GroupEnd();
     if (prev >= 0) (void)hipSetDevice(prev);
-    if (r != ncclSuccess) return fail(CASTER_HIP_ERR_DEVICE, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(r));
+    if (r != ncclSuccess) {
+        // the group did not start as a whole: the communicators are not to be trusted again
+        for (ncclComm_t c : g_rccl.comms)
+            if (c) (void)g_rccl.CommAbort(c);
+        g_rccl.comms.clear();
+        g_rccl.devices.clear();
+        return fail(CASTER_HIP_ERR_DEVICE, "ncclGroupEnd failed: %s; the communicators were ended", g_rccl.GetErrorString(r));
+    }
     return CASTER_HIP_OK;
 }

@@ -128,10 +128,17 @@ clock_t ray_dispatcher_worker_fence(ray_dispatcher* rd);
 
 /* Render options the reference fixes at compile time; call before run_jobs. */
 void ray_dispatcher_set_seed(ray_dispatcher* rd, u32 seed);
-void ray_dispatcher_set_strict(ray_dispatcher* rd, int strict);
+void ray_dispatcher_set_strict(ray_dispatcher* rd, int strict);   /* default 1: the reference's operation order (the parity-checked mode); 0 = fast */
 void ray_dispatcher_set_batch(ray_dispatcher* rd, i32 samples_per_batch);
 /* More jobs than devices (job g on device g % devices, own context and sample range each). */
 void ray_dispatcher_set_jobs(ray_dispatcher* rd, i32 jobs);
+
+/* The order in which the fence adds the jobs' buffers (see dispatcher.c): same-device adds into the
+ * first job of each device, then one RCCL reduce over the devices' leads or, without RCCL, a pairwise
+ * tree.  Pure functions of the job -> device map; exported so that the order is testable without a GPU. */
+typedef struct { int dst, src, round; } crt_sum_step;
+int crt_sum_plan_local(const int* device, int n_jobs, int* lead, crt_sum_step* steps, int* n_steps);
+int crt_sum_plan_tree(int n_lead, crt_sum_step* steps);
 
 /* Progressive accumulation across runs (the reference plans a "gradual image add mode",
  * src/dispatcher.c:6-7).  set_checkpoint: the fence writes the frame's radiance sums and the sample

@@ -169,7 +169,7 @@ ray_dispatcher new_ray_dispatcher(u8 num_threads, u8 blocks, i32 width, i32 heig
         be->n_jobs = n_jobs;
         be->n_dev = n_dev > 0 ? n_dev : 1;
         be->seed = 0xC0FFEEu;
-        be->strict = 0;
+        be->strict = 1;                       /* the reference's operation order: the parity-checked mode */
         be->batch = 0;
         be->flat = crt_flatten(list);
         if (!be->flat) {
@@ -244,40 +244,81 @@ void ray_dispatcher_run_jobs(ray_dispatcher* rd)
     }
 }
 
+/* The order in which a frame's buffers are added, as data (so that it can be checked without a GPU).
+ * crt_sum_plan_local: the first job on each device leads it; every other job is added into its
+ * device's lead (steps {dst job, src job}, in job order).  lead[] receives the leads' job numbers in
+ * the order the devices first appear; job 0 is always lead[0].  Returns the number of leads.
+ * crt_sum_plan_tree: the pairwise tree over n_lead buffers, rounds of stride 1, 2, 4, ...: in a round
+ * lead l (a multiple of 2*stride) takes lead l + stride.  Steps hold positions in lead[]; the
+ * adds of one round touch disjoint buffers and may run concurrently; after the last round lead[0]
+ * holds the sum.  Returns the number of steps. */
+int crt_sum_plan_local(const int* device, int n_jobs, int* lead, crt_sum_step* steps, int* n_steps)
+{
+    int n_lead = 0, n = 0;
+    for (int g = 0; g < n_jobs; g++) {
+        int l = 0;
+        while (l < n_lead && device[lead[l]] != device[g]) l++;
+        if (l == n_lead) { lead[n_lead++] = g; continue; }
+        steps[n].dst = lead[l]; steps[n].src = g; steps[n].round = 0;
+        n++;
+    }
+    *n_steps = n;
+    return n_lead;
+}
+
+int crt_sum_plan_tree(int n_lead, crt_sum_step* steps)
+{
+    int n = 0, round = 1;
+    for (int stride = 1; stride < n_lead; stride *= 2, round++)
+        for (int l = 0; l + stride < n_lead; l += 2 * stride) {
+            steps[n].dst = l; steps[n].src = l + stride; steps[n].round = round;
+            n++;
+        }
+    return n;
+}
+
 /* The sum of the jobs' radiance sums into job 0's buffer; they are linear and must be added before
  * the scale and the gamma (src/dispatcher.c:29-30).  Jobs that share a GPU are added into the first
  * job on that GPU with an add kernel; the per-GPU sums then meet in ONE RCCL reduce over the node's
  * xGMI links (caster_hip_reduce), everything queued on the GPUs' streams without a host wait in
  * between.  Without RCCL the per-GPU sums are added pairwise over the peer links instead -- a tree of
- * log2(G) rounds whose adds run concurrently -- and a line on stderr says so. */
+ * log2(G) rounds whose adds run concurrently -- and a line on stderr says so.  A failed
+ * caster_hip_reduce has queued nothing (it ends its communicators before any part of the collective
+ * is launched), so the streams are free for the fallback. */
 static int sum_jobs(gpu_backend* be, size_t n_floats, const char** how)
 {
-    gpu_job* lead[MAX_THREADS];
-    int n_lead = 0, rc = 0;
+    int device[MAX_THREADS], lead[MAX_THREADS];
+    crt_sum_step steps[MAX_THREADS];
+    int n_steps = 0, rc = 0;
     *how = "one buffer";
-    for (int g = 0; g < be->n_jobs; g++) {
-        gpu_job* job = &be->jobs[g];
-        int l = 0;
-        while (l < n_lead && lead[l]->device != job->device) l++;
-        if (l == n_lead) { lead[n_lead++] = job; continue; }
+    for (int g = 0; g < be->n_jobs; g++) device[g] = be->jobs[g].device;
+    const int n_lead = crt_sum_plan_local(device, be->n_jobs, lead, steps, &n_steps);
+    for (int k = 0; k < n_steps; k++) {
+        gpu_job* dst = &be->jobs[steps[k].dst];
+        gpu_job* src = &be->jobs[steps[k].src];
         *how = "add kernels";
-        if ((rc = caster_hip_add_from_device(lead[l]->ctx, lead[l]->accum_dev, job->device, job->accum_dev, n_floats))) return rc;
+        if ((rc = caster_hip_add_from_device(dst->ctx, dst->accum_dev, src->device, src->accum_dev, n_floats))) return rc;
     }
     if (n_lead > 1) {
         caster_hip_ctx* ctxs[MAX_THREADS];
         float* bufs[MAX_THREADS];
-        for (int l = 0; l < n_lead; l++) { ctxs[l] = lead[l]->ctx; bufs[l] = lead[l]->accum_dev; }
+        for (int l = 0; l < n_lead; l++) { ctxs[l] = be->jobs[lead[l]].ctx; bufs[l] = be->jobs[lead[l]].accum_dev; }
         *how = "RCCL reduce";
         rc = caster_hip_reduce(ctxs, bufs, n_lead, n_floats);
         if (rc) {
             fprintf(stderr, "fence: %s; adding the %d GPUs' sums pairwise over the peer links instead\n", caster_hip_last_error(), n_lead);
             *how = "pairwise peer adds";
             rc = 0;
-            for (int stride = 1; stride < n_lead && !rc; stride *= 2) {
-                for (int l = 0; l < n_lead && !rc; l++) rc = caster_hip_synchronize(lead[l]->ctx);    /* sources complete */
-                for (int l = 0; l + stride < n_lead && !rc; l += 2 * stride)
-                    rc = caster_hip_add_from_device(lead[l]->ctx, lead[l]->accum_dev, lead[l + stride]->device,
-                                                    lead[l + stride]->accum_dev, n_floats);
+            const int n_tree = crt_sum_plan_tree(n_lead, steps);
+            int round = 0;
+            for (int k = 0; k < n_tree && !rc; k++) {
+                if (steps[k].round != round) {                   /* a new round: its sources must be complete */
+                    round = steps[k].round;
+                    for (int l = 0; l < n_lead && !rc; l++) rc = caster_hip_synchronize(ctxs[l]);
+                }
+                if (!rc)
+                    rc = caster_hip_add_from_device(ctxs[steps[k].dst], bufs[steps[k].dst], be->jobs[lead[steps[k].src]].device,
+                                                    bufs[steps[k].src], n_floats);
             }
         }
     }

@@ -3,7 +3,7 @@
  * same camera, same output file; the preview window is left out.
  *
  *   craytracer <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|perlin|stress:N]
- *              [--seed S] [--strict] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp]
+ *              [--seed S] [--strict | --fast] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp]
  *              [--checkpoint file] [--resume file]
  *
  * --checkpoint writes the frame's radiance sums and sample ranges; --resume starts from such a
@@ -18,7 +18,7 @@ int main(int argc, char* argv[])
 {
     if (argc < 5) {
         fprintf(stderr, "usage: %s <height> <spp> <max_depth> <gpus> [--scene 0|rtiow|perlin|stress:N] [--seed S] "
-                        "[--strict] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp] [--checkpoint file] "
+                        "[--strict | --fast] [--batch B] [--jobs J] [--texture file.bmp] [--out file.bmp] [--checkpoint file] "
                         "[--resume file]\n", argv[0]);
         return 2;
     }
@@ -35,12 +35,13 @@ int main(int argc, char* argv[])
     const char* checkpoint_name = NULL;
     const char* resume_name = NULL;
     u32 seed = 0xC0FFEEu;
-    int strict = 0;
+    int strict = 1;                                  /* the reference's arithmetic; --fast trades it for speed */
     i32 batch = 0, jobs = 0;
     for (int k = 5; k < argc; k++) {
         if (!strcmp(argv[k], "--scene") && k + 1 < argc) scene_name = argv[++k];
         else if (!strcmp(argv[k], "--seed") && k + 1 < argc) seed = (u32)strtoul(argv[++k], NULL, 0);
         else if (!strcmp(argv[k], "--strict")) strict = 1;
+        else if (!strcmp(argv[k], "--fast")) strict = 0;
         else if (!strcmp(argv[k], "--batch") && k + 1 < argc) batch = atoi(argv[++k]);
         else if (!strcmp(argv[k], "--jobs") && k + 1 < argc) jobs = atoi(argv[++k]);
         else if (!strcmp(argv[k], "--texture") && k + 1 < argc) texture_name = argv[++k];

@@ -131,6 +131,10 @@ int caster_hip_memset_zero(caster_hip_ctx* ctx, void* dev_ptr, size_t bytes);
 int caster_hip_download(caster_hip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
 int caster_hip_upload(caster_hip_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 int caster_hip_synchronize(caster_hip_ctx* ctx);
+/* Free and total device memory of the context's GPU right now (hipMemGetInfo); either pointer may
+ * be NULL.  The reference has no counterpart (it allocates on the host heap, src/image.c:5); hosts
+ * use it to size frames, the tests to show that caster_hip_render_noalloc allocates nothing. */
+int caster_hip_mem_info(caster_hip_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 
 /* dst_dev[i] += src_dev[i] for n_floats floats, where src_dev lives on device src_device (memory
  * of another context, whose work on it has completed) and dst_dev on ctx's device: a peer-to-peer
@@ -166,8 +170,11 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
                       int sample_begin, int sample_count, int max_depth,
                       uint32_t seed, uint32_t flags, float* accum_dev);
 
-/* caster_hip_render for callers that cannot allocate device memory (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+/* caster_hip_render for callers that cannot allocate device memory (tight serving loops, harnesses
+ * that forbid hipMalloc, code that must not allocate because a HIP graph is being captured elsewhere
+ * in the process).  It has no counterpart in the reference.  The call itself is an eager call: it
+ * records the two timing events that caster_hip_render_stats / _info read, and those two wait on the
+ * stream -- neither is allowed ON a capturing stream, and the call has not been exercised there.
  * Same arguments, same result bit for bit, same asynchrony; it calls no hipMalloc/hipFree or any
  * other allocating routine: the scratch that caster_hip_render keeps in buffers it allocates on
  * first use (the per-pixel fixed-point sums of the call, the ray and trip counters, the work

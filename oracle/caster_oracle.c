@@ -564,6 +564,7 @@ typedef struct {
     const ocam* cam;
     int width, height, spp, max_depth, j0, j1;
     uint32_t seed;
+    int rng_mode;
     float* sums;
     int64_t rays;
 } orc_job;
@@ -572,7 +573,7 @@ static void* orc_job_main(void* arg)
 {
     orc_job* job = (orc_job*)arg;
     job->rays = orc_render_rows(job->sc, job->cam, job->width, job->height, job->j0, job->j1, 0,
-                                job->spp, job->max_depth, job->seed, ORC_RNG_COUNTER, job->sums);
+                                job->spp, job->max_depth, job->seed, job->rng_mode, job->sums);
     return NULL;
 }
 
@@ -582,6 +583,17 @@ static void* orc_job_main(void* arg)
 int64_t orc_dispatch(const oscene* sc, const ocam* cam, int width, int height, int spp,
                      int max_depth, uint32_t seed, int threads, int blocks,
                      float* sums, uint8_t* rgba)
+{
+    return orc_dispatch_rng(sc, cam, width, height, spp, max_depth, seed, threads, blocks,
+                            ORC_RNG_COUNTER, sums, rgba);
+}
+
+/* The same dispatcher with the random source chosen.  ORC_RNG_LIBC is the reference as it
+ * ships: every thread draws from the one libc rand() (src/common.c:10-13), whose hidden state
+ * glibc guards with a lock, so the threads serialise on it and the image is not reproducible. */
+int64_t orc_dispatch_rng(const oscene* sc, const ocam* cam, int width, int height, int spp,
+                         int max_depth, uint32_t seed, int threads, int blocks, int rng_mode,
+                         float* sums, uint8_t* rgba)
 {
     if (threads > 64) threads = 64; /* MAX_THREADS, inc/dispatcher.h:10 */
     if (threads < 1) threads = 1;
@@ -594,6 +606,7 @@ int64_t orc_dispatch(const oscene* sc, const ocam* cam, int width, int height, i
         orc_job* jb = &jobs[k];
         jb->sc = sc; jb->cam = cam; jb->width = width; jb->height = height;
         jb->spp = spp; jb->max_depth = max_depth; jb->seed = seed; jb->sums = sums;
+        jb->rng_mode = rng_mode;
         jb->j0 = k * block_size;
         jb->j1 = (k + 1) * block_size;
         if (jb->j0 > height) jb->j0 = height;

@@ -163,6 +163,11 @@ void orc_resolve(const float* sums, int width, int height, int spp, uint8_t* rgb
 int64_t orc_dispatch(const oscene* sc, const ocam* cam, int width, int height, int spp,
                      int max_depth, uint32_t seed, int threads, int blocks,
                      float* sums, uint8_t* rgba);
+/* The same with the random source chosen: ORC_RNG_LIBC has every thread draw from the one libc
+ * rand() as src/common.c:10-13 does (glibc serialises the calls on a lock). */
+int64_t orc_dispatch_rng(const oscene* sc, const ocam* cam, int width, int height, int spp,
+                         int max_depth, uint32_t seed, int threads, int blocks, int rng_mode,
+                         float* sums, uint8_t* rgba);
 
 /* Bytes of the BMP that src/image.c:98-196 writes for an RGBA8 buffer.
  * out must hold 54 + height*stride bytes; returns the byte count. */

@@ -57,6 +57,7 @@ def lib():
         l = C.CDLL(_LIB)
         l.orc_render_rows.restype = C.c_int64
         l.orc_dispatch.restype = C.c_int64
+        l.orc_dispatch_rng.restype = C.c_int64
         l.orc_bmp_bytes.restype = C.c_int64
         l.orc_calculate_cam_info.restype = _OCam
         l.orc_calculate_cam_info.argtypes = [_OV3, _OV3, _OV3, C.c_float, C.c_float, C.c_float, C.c_float]
@@ -116,13 +117,15 @@ def render(scene: Scene, cam, width, height, spp, max_depth, seed, sample_begin=
     return sums, int(rays)
 
 
-def dispatch(scene: Scene, cam, width, height, spp, max_depth, seed, threads, blocks=None):
-    """pthread port of the reference dispatcher; returns (sums, rgba [h, w, 4] uint8, rays)."""
+def dispatch(scene: Scene, cam, width, height, spp, max_depth, seed, threads, blocks=None, rng_mode=RNG_COUNTER):
+    """pthread port of the reference dispatcher; returns (sums, rgba [h, w, 4] uint8, rays).
+    rng_mode RNG_LIBC: every thread draws from the one libc rand(), as the reference ships."""
     cam = _f32(cam, (19,))
     sums = np.zeros((height, width, 4), dtype=np.float32)
     rgba = np.zeros((height, width, 4), dtype=np.uint8)
-    rays = lib().orc_dispatch(C.byref(scene.c), _p(cam), C.c_int(width), C.c_int(height), C.c_int(spp), C.c_int(max_depth),
-                              C.c_uint32(seed), C.c_int(threads), C.c_int(blocks if blocks else threads), _p(sums), _p(rgba))
+    rays = lib().orc_dispatch_rng(C.byref(scene.c), _p(cam), C.c_int(width), C.c_int(height), C.c_int(spp), C.c_int(max_depth),
+                                  C.c_uint32(seed), C.c_int(threads), C.c_int(blocks if blocks else threads), C.c_int(rng_mode),
+                                  _p(sums), _p(rgba))
     return sums, rgba, int(rays)
 
 

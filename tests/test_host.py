@@ -232,3 +232,58 @@ def test_sample_range_lists_and_checkpoint_file(tmp_path, ca):
         open(p, "wb").write(blob)
         assert not host.crt_checkpoint_read(p)
     assert not host.crt_checkpoint_read(str(tmp_path / "missing").encode())
+
+
+class _SumStep(ctypes.Structure):
+    _fields_ = [("dst", ctypes.c_int), ("src", ctypes.c_int), ("round", ctypes.c_int)]
+
+
+def _fence_sum(host, device):
+    """Runs the fence's summation plan for a job -> device map on integer stand-ins for the buffers
+    (job g holds 1 << g, so any sum names exactly the jobs it contains)."""
+    n = len(device)
+    dev = (ctypes.c_int * n)(*device)
+    lead = (ctypes.c_int * 64)()
+    steps = (_SumStep * 64)()
+    n_steps = ctypes.c_int()
+    n_lead = host.crt_sum_plan_local(dev, n, lead, steps, ctypes.byref(n_steps))
+    buf = [1 << g for g in range(n)]
+    for k in range(n_steps.value):
+        assert steps[k].round == 0 and device[steps[k].dst] == device[steps[k].src]      # an add kernel never crosses devices
+        buf[steps[k].dst] += buf[steps[k].src]
+    leads = [lead[l] for l in range(n_lead)]
+    return buf, leads, steps
+
+
+def test_fence_sum_plan_leads_and_tree_order(ca):
+    """The order in which the fence adds the jobs' buffers, checked as data: the first job of each
+    device leads it, every job's buffer is added exactly once, job 0 ends up with the frame; the
+    pairwise tree (the route without RCCL) adds disjoint pairs per round and finishes in ceil(log2 G) rounds."""
+    host = ca.load_host_lib()
+    for device in ([0], [0, 0, 0], [0, 1, 2, 3], [0, 1, 2, 3, 4, 5, 6, 7], [0, 1, 0, 1, 0], [3, 3, 1, 3, 1, 0, 2, 2, 0],
+                   list(range(8)) * 2, [g % 3 for g in range(11)]):
+        n = len(device)
+        buf, leads, steps = _fence_sum(host, device)
+        assert leads[0] == 0
+        assert [device[l] for l in leads] == list(dict.fromkeys(device))        # one lead per device, in order of first use
+        assert sorted(set(device)) == sorted(device[l] for l in leads)
+        for d in set(device):                                                    # a lead holds exactly its device's jobs
+            l = [x for x in leads if device[x] == d][0]
+            assert buf[l] == sum(1 << g for g in range(n) if device[g] == d)
+        # the tree over the leads
+        n_lead = len(leads)
+        n_tree = host.crt_sum_plan_tree(n_lead, steps)
+        assert n_tree == n_lead - 1
+        val = [buf[l] for l in leads]
+        rounds = {}
+        for k in range(n_tree):
+            rounds.setdefault(steps[k].round, []).append((steps[k].dst, steps[k].src))
+        assert sorted(rounds) == list(range(1, len(rounds) + 1))
+        assert len(rounds) == (0 if n_lead == 1 else int(np.ceil(np.log2(n_lead))))
+        for r in sorted(rounds):
+            touched = [x for pair in rounds[r] for x in pair]
+            assert len(touched) == len(set(touched))                             # the adds of a round are independent
+            for dst, src in rounds[r]:
+                val[dst] += val[src]
+                val[src] = 0                                                     # consumed: must not be added again
+        assert val[0] == (1 << n) - 1                                            # every job exactly once, in job 0's buffer

@@ -342,3 +342,18 @@ def test_counter_rng_render_agrees_with_the_libc_rand_golden(orc, ca):
     assert 28.0 < psnr < 36.0, psnr
     assert abs(diff.mean()) < 1.5 / 255, diff.mean()                      # sqrt of a noisy mean is biased low by ~var/(8 m^1.5)
     assert abs(rays / (w * h * spp) - float(gold["rtiow_rays"]) / (w * h * spp_ref)) < 0.03
+
+
+def test_dispatch_on_libc_rand_is_the_same_renderer(orc):
+    """The as-shipped leg of the CPU baseline (every thread draws from the one libc rand(), src/common.c:10-13)
+    is the same renderer as the keyed port: same frame up to Monte-Carlo noise, a comparable ray count."""
+    import craytracer_amd as ca
+
+    fs = ca.scene_rtiow(1)
+    cam = ca.default_camera(16 / 9)
+    sc = orc.Scene.from_flat(fs)
+    a, _, rays_a = orc.dispatch(sc, cam, 64, 36, 16, 50, 5, 4)
+    b, _, rays_b = orc.dispatch(sc, cam, 64, 36, 16, 50, 5, 4, rng_mode=orc.RNG_LIBC)
+    assert abs(rays_a - rays_b) < 0.1 * rays_a
+    assert np.all(a[..., 3] == 16) and np.all(b[..., 3] == 16)
+    assert abs(a[..., :3].mean() - b[..., :3].mean()) < 0.1 * a[..., :3].mean()

@@ -42,6 +42,33 @@ def test_no_alloc_render_equals_render(gpu, ca):
     assert ia["rays"] == ib["rays"] and np.array_equal(ha, hb) and ia["loop"] == "vector"
 
 
+def test_no_alloc_render_allocates_nothing(gpu, ca):
+    """The property the entry point exists for: the GPU's free memory is the same before and after
+    calls of caster_hip_render_noalloc, the first of them on a frame larger than anything
+    caster_hip_render has seen on this context (a fresh one, so no scratch of an earlier frame covers it)."""
+    with ca.CasterHip(0) as fresh:
+        fresh.upload_scene(ca.scene_rtiow(1))
+        w, h = 1024, 1000                                   # 1 024 000 pixels: just under the limit
+        acc = fresh.malloc(w * h * 16)
+        try:
+            fresh.memset_zero(acc, w * h * 16)
+            fresh.render(ca.default_camera(1.0), 64, 64, 0, 1, 5, 1, acc, strict=True)      # warms the library up on a small frame
+            fresh.synchronize()
+            free0, total = fresh.mem_info()
+            assert 0 < free0 <= total
+            for (fw, fh, spp) in ((w, h, 1), (300, 200, 2), (w, h, 1)):
+                fresh.render_noalloc(ca.default_camera(fw / fh), fw, fh, 0, spp, 50, 9, acc, strict=True)
+                info = fresh.render_info()
+                assert info["rays"] >= fw * fh * spp
+                assert fresh.mem_info()[0] == free0
+            # the allocating entry point on the large frame does take memory (the check can see it): its scratch grows
+            fresh.render(ca.default_camera(w / h), w, h, 0, 1, 50, 9, acc, strict=True)
+            fresh.synchronize()
+            assert fresh.mem_info()[0] < free0
+        finally:
+            fresh.free(acc)
+
+
 def test_no_alloc_limits(gpu, ca):
     gpu.upload_scene(ca.scene_0())
     acc = gpu.malloc(16)

@@ -16,12 +16,17 @@ of a pass (the 8 XCDs report separately):
   mfma_busy_frac         SQ_VALU_MFMA_BUSY_CYCLES / simd_cycles
   lds_conflict_share     SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS
   hbm bytes              2 x FETCH_SIZE KB (gfx950 reports half of wide reads) + WRITE_SIZE KB, per launch
+Both output files carry the hash of the kernel sources in the tree (craytracer_amd/buildinfo.py).
 """
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from craytracer_amd.buildinfo import kernel_source_hash  # noqa: E402
 
 
 def read_pass_dir(path):
@@ -84,7 +89,7 @@ def main():
                         "wave_trips": float(trips), "figures": fig, "raw": c})
         if loop.startswith("matrix") and "hbm_bytes_per_launch" in fig:
             with open(prefix + "_hbm_traffic.json", "w") as f:
-                json.dump({"workload": workload, "arithmetic_mode": mode, "kernel": names, "FETCH_SIZE_KB": c["FETCH_SIZE"],
+                json.dump({"kernel_source_hash": kernel_source_hash(), "workload": workload, "arithmetic_mode": mode, "kernel": names, "FETCH_SIZE_KB": c["FETCH_SIZE"],
                            "WRITE_SIZE_KB": c["WRITE_SIZE"], "bytes_per_launch": fig["hbm_bytes_per_launch"],
                            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc.sh), one launch each, summed "
                                   "over XCDs; bytes = 2 x FETCH_SIZE x 1024 (gfx950 reports half of wide reads) + WRITE_SIZE x 1024; the writes are "
@@ -92,7 +97,9 @@ def main():
                                   "and as a 32-byte request otherwise (tools/atomic_traffic.hip)"}, f, indent=1)
     with open(prefix + "_pmc_summary.json", "w") as f:
         json.dump({"how": "rocprofv3 --pmc, separate passes (tools/pmc.sh), one launch of the render kernel per pass; "
-                          "figures derived by tools/pmc_summary.py", "kernels": kernels}, f, indent=1)
+                          "figures derived by tools/pmc_summary.py; kernel_source_hash = craytracer_amd.buildinfo.kernel_source_hash() "
+                          "of the tree the passes ran on (bench.py quotes the figures only for that tree)",
+                   "kernel_source_hash": kernel_source_hash(), "kernels": kernels}, f, indent=1)
     for k in kernels:
         print(k["workload"], k["arithmetic_mode"], k["loop"], json.dumps(k["figures"]))
 
