@@ -38,7 +38,7 @@ class CasterHipError(RuntimeError):
 
 class _RenderInfo(C.Structure):      # caster_render_info
     _fields_ = [("loop_kind", C.c_int32), ("mfma_blocks", C.c_int32), ("n_spheres", C.c_int32), ("kernel_ms", C.c_float),
-                ("rays", C.c_uint64), ("wave_trips", C.c_uint64)]
+                ("rays", C.c_uint64), ("wave_trips", C.c_uint64), ("primary_batches", C.c_uint64)]
 
 
 NOALLOC_MAX_PIXELS = 1 << 20         # CASTER_HIP_NOALLOC_MAX_PIXELS
@@ -393,7 +393,8 @@ class CasterHip:
         info = _RenderInfo()
         _check(self._lib.caster_hip_render_info(self._ctx, C.byref(info)), "caster_hip_render_info")
         return dict(loop_kind=info.loop_kind, loop=LOOP_NAMES.get(info.loop_kind, "none"), mfma_blocks=info.mfma_blocks,
-                    n_spheres=info.n_spheres, kernel_ms=info.kernel_ms, rays=info.rays, wave_trips=info.wave_trips)
+                    n_spheres=info.n_spheres, kernel_ms=info.kernel_ms, rays=info.rays, wave_trips=info.wave_trips,
+                    primary_batches=info.primary_batches)
 
     def render_stats(self):
         rays, ms = C.c_uint64(), C.c_float()

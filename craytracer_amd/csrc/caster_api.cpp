@@ -48,7 +48,9 @@ constexpr int kCounterWords = 4;
 // host code the name is only a handle for hipGetSymbolAddress (caster_hip_create asks once per
 // device and keeps the pointer); kernels and hipMemsetAsync are given that pointer, never the name.
 constexpr size_t kNoAllocMaxPixels = (size_t)CASTER_HIP_NOALLOC_MAX_PIXELS;
-static __device__ __align__(256) unsigned long long scratch[kCounterWords + 3 * kNoAllocMaxPixels];
+constexpr size_t kNoAllocMaxWaves = (size_t)CASTER_HIP_NOALLOC_MAX_WAVES;
+constexpr size_t kRingWords64 = caster::kRingBytesPerWave / sizeof(unsigned long long);     // per wave
+static __device__ __align__(256) unsigned long long scratch[kCounterWords + 3 * kNoAllocMaxPixels + kNoAllocMaxWaves * kRingWords64];
 
 namespace {
 constexpr int kMaxDevices = 64;
@@ -69,7 +71,8 @@ struct caster_hip_ctx {
     // scratch
     unsigned long long* fixed = nullptr;      // per-pixel fixed-point sums of the call in flight
     size_t fixed_bytes = 0;
-    unsigned long long* counters = nullptr;   // kCounterWords words: [0] rays, [1] low word: work-unit queue head, [2] wave trips
+    unsigned long long* counters = nullptr;   // kCounterWords words: [0] rays, [1] low word: work-unit queue head, [2] wave trips, [3] camera-ray batches
+    uint32_t* ring = nullptr;                 // the waves' rings of waiting paths: kRingBytesPerWave for each of resident_blocks * 4 waves
     unsigned long long* scratch = nullptr;    // this device's copy of the static scratch array (caster_hip_render_noalloc)
     int resident_blocks = 1024;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -188,7 +191,8 @@ int caster_hip_create(int device, caster_hip_ctx** out)
     }
     const char* env_chunk = getenv("CASTER_HIP_CHUNK");
     if (env_chunk) ctx->chunk = atoi(env_chunk);
-    if (hipMalloc(reinterpret_cast<void**>(&ctx->counters), kCounterWords * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void**>(&ctx->ring), (size_t)ctx->resident_blocks * caster::kWavesPerBlock * caster::kRingBytesPerWave) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->counters), kCounterWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->counters, 0, kCounterWords * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         caster_hip_destroy(ctx);
@@ -222,6 +226,7 @@ int caster_hip_destroy(caster_hip_ctx* ctx)
     if (ctx->fixed) (void)hipFree(ctx->fixed);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->ring) (void)hipFree(ctx->ring);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -578,7 +583,7 @@ static int plan_chunks(const caster_hip_ctx* ctx, int width, int height, int sam
 // the static array.  Nothing here allocates.
 static int render_on(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height, int sample_begin,
                      int sample_count, int max_depth, uint32_t seed, uint32_t flags, float* accum_dev,
-                     unsigned long long* fixed, unsigned long long* counters)
+                     unsigned long long* fixed, unsigned long long* counters, uint32_t* ring, int ring_waves)
 {
     HIP_TRY(hipMemsetAsync(counters, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
     ctx->render_pending = true;
@@ -607,6 +612,9 @@ static int render_on(caster_hip_ctx* ctx, const caster_camera* cam, int width, i
     a.rays = counters;
     a.queue = reinterpret_cast<unsigned int*>(counters + 1);
     a.trips = counters + 2;
+    a.batches = counters + 3;
+    a.ring = ring;
+    a.ring_waves = ring_waves;
     a.n_units = 0;
     a.lds_spheres = 0;
     const int strict = (flags & CASTER_HIP_STRICT) ? 1 : 0;
@@ -653,7 +661,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
         ctx->fixed_bytes = need;
     }
     return render_on(ctx, cam, width, height, sample_begin, sample_count, max_depth, seed, flags, accum_dev,
-                     ctx->fixed, ctx->counters);
+                     ctx->fixed, ctx->counters, ctx->ring, ctx->resident_blocks * caster::kWavesPerBlock);
 }
 
 int caster_hip_render_noalloc(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height,
@@ -667,9 +675,13 @@ int caster_hip_render_noalloc(caster_hip_ctx* ctx, const caster_camera* cam, int
                                         "use caster_hip_render or render the frame in parts",
                     width, height, (size_t)width * (size_t)height, kNoAllocMaxPixels);
     if (!ctx->scratch) return fail(CASTER_HIP_ERR_STATE, "no scratch address for device %d", ctx->device);
+    if ((size_t)ctx->resident_blocks * caster::kWavesPerBlock > kNoAllocMaxWaves)
+        return fail(CASTER_HIP_ERR_ARG, "caster_hip_render_noalloc: this GPU runs %d waves of the render kernel at a time, the static "
+                                        "scratch holds the path rings of %zu", ctx->resident_blocks * caster::kWavesPerBlock, kNoAllocMaxWaves);
     DeviceGuard guard(ctx->device);
     return render_on(ctx, cam, width, height, sample_begin, sample_count, max_depth, seed, flags, accum_dev,
-                     ctx->scratch + kCounterWords, ctx->scratch);
+                     ctx->scratch + kCounterWords, ctx->scratch,
+                     reinterpret_cast<uint32_t*>(ctx->scratch + kCounterWords + 3 * kNoAllocMaxPixels), (int)kNoAllocMaxWaves);
 }
 
 int caster_hip_add_from_device(caster_hip_ctx* ctx, float* dst_dev, int src_device, const float* src_dev, size_t n_floats)
@@ -727,6 +739,7 @@ int caster_hip_render_info(caster_hip_ctx* ctx, caster_render_info* out)
     out->n_spheres = ctx->last_spheres;
     out->rays = (uint64_t)c[0];
     out->wave_trips = (uint64_t)c[2];
+    out->primary_batches = (uint64_t)c[3];
     HIP_TRY(hipEventElapsedTime(&out->kernel_ms, ctx->ev0, ctx->ev1));
     return CASTER_HIP_OK;
 }

@@ -67,6 +67,13 @@ inline int pick_loop_kind(const SceneDev& s, int strict)
 
 constexpr int kMaxChunks = 256;
 
+// Paths between their first and their second ray wait in a ring of the wave in device memory (see
+// "primary rays" in caster_render.hpp): kRingEntries path states of kRingWords 32-bit words, word-major.
+constexpr int kRingEntries = 128;
+constexpr int kRingWords = 17;
+constexpr size_t kRingBytesPerWave = (size_t)kRingEntries * kRingWords * sizeof(uint32_t);
+constexpr int kWavesPerBlock = 4;
+
 struct RenderArgs {
     CamRec cam;
     SceneDev scene;
@@ -80,6 +87,9 @@ struct RenderArgs {
     unsigned long long* rays;
     unsigned int* queue;     // work-unit queue head, zero at launch
     unsigned long long* trips; // wave trips through the sphere loop (128 ray slots each), zero at launch
+    unsigned long long* batches; // batches of 64 camera rays traced against their tile's sphere list, zero at launch
+    uint32_t* ring;          // kRingBytesPerWave bytes for every wave of the launch; contents need no initialisation
+    int ring_waves;          // waves the ring buffer has room for
     int n_units;             // filled in by the launcher
     int lds_spheres;         // float4 slots per sphere image in LDS (filled in by the launcher)
 };

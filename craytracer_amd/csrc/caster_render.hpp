@@ -49,14 +49,27 @@ CDEV f2 splat(float x) { return f2{x, x}; }
 
 struct Slot {
     V3 o, d;        // strict: d as the reference has it; fast: unit length
-    float aa;       // strict: d.d ; fast: 1
-    float tmin;     // strict: 0.001 ; fast: 0.001 * |d|
-    float tmax;     // strict: 16777215 ; fast: 16777215 * |d|
+#if CASTER_STRICT
+    float aa_;      // d.d
+#else
+    float tmin_;    // 0.001 * |d| of the ray as the reference has it (t is measured along the unit direction)
+    float tmax_;    // 16777215 * |d|
+#endif
     V3 thr;         // product of the attenuations so far
     Rng g;
     int q;          // pixel this path belongs to: column in bits 0-15, row in bits 16-31
-    int depth;      // rays this path may still shoot
-    bool alive;
+    int depth;      // rays this path may still shoot; 0: the slot holds no path
+    CDEV bool alive() const { return depth > 0; }
+    // d.d, and the range of t (src/caster.c:441): constants of the mode where they are not stored
+#if CASTER_STRICT
+    CDEV float aa() const { return aa_; }
+    CDEV float tmin() const { return kTMin; }
+    CDEV float tmax() const { return kTMax; }
+#else
+    CDEV float aa() const { return 1.0f; }
+    CDEV float tmin() const { return tmin_; }
+    CDEV float tmax() const { return tmax_; }
+#endif
 };
 
 // A slot without a path: a ray that starts far outside any scene and misses
@@ -66,10 +79,13 @@ CDEV void park(Slot& s)
 {
     s.o = mk(0.0f, 1.0e15f, 0.0f);
     s.d = mk(1.0f, 0.0f, 0.0f);
-    s.aa = 1.0f;
-    s.tmin = kTMin;
-    s.tmax = kTMax;
-    s.alive = false;
+#if CASTER_STRICT
+    s.aa_ = 1.0f;
+#else
+    s.tmin_ = kTMin;
+    s.tmax_ = kTMax;
+#endif
+    s.depth = 0;
 }
 
 CDEV void set_ray(Slot& s, const Ray& r)
@@ -77,18 +93,15 @@ CDEV void set_ray(Slot& s, const Ray& r)
     s.o = r.o;
 #if CASTER_STRICT
     s.d = r.d;
-    s.aa = dot(r.d, r.d);
-    s.tmin = kTMin;
-    s.tmax = kTMax;
+    s.aa_ = dot(r.d, r.d);
 #else
     // t is measured along the unit direction: t' = t * |d|
     const float len2 = dot(r.d, r.d);
     const float inv = __frsqrt_rn(len2);
     const float len = len2 * inv;
     s.d = r.d * inv;
-    s.aa = 1.0f;
-    s.tmin = kTMin * len;
-    s.tmax = kTMax * len;
+    s.tmin_ = kTMin * len;
+    s.tmax_ = kTMax * len;
 #endif
 }
 
@@ -196,19 +209,6 @@ CDEV void start_pool_path(Slot& s, int m, const Unit& un, const RenderArgs& a, c
     s.thr = mk(1.0f, 1.0f, 1.0f);
     s.q = (j << 16) | i;
     s.depth = a.max_depth;
-    s.alive = true;
-}
-
-// Slots without a path take the next entries of the unit's pool, in lane order.
-CDEV void refill(Slot& s, Unit& un, const RenderArgs& a, const Cam& cam, const PixelScale& ps)
-{
-    if (un.chunk < 0 || un.next >= un.total) return;             // wave-uniform
-    const unsigned long long want = __ballot(!s.alive);
-    if (want == 0ull) return;
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
-    const int m = un.next + rank;
-    if (!s.alive && m < un.total) { CASTER_STAT(11); start_pool_path(s, m, un, a, cam, ps); }
-    un.next += __popcll(want);
 }
 
 // Adds the sums of a unit's tile to the frame's fixed-point buffer and clears the accumulator.  The
@@ -302,7 +302,7 @@ CDEV PairRays pack_rays(const Slot& sa, const Slot& sb, const float3 ref)
     const f2 qz = f2{sa.o.z, sb.o.z} - splat(ref.z);
 #if CASTER_STRICT
     // the slots keep the reference's unnormalised direction; the filter wants a unit one
-    const f2 inv = f2{__frsqrt_rn(sa.aa), __frsqrt_rn(sb.aa)};
+    const f2 inv = f2{__frsqrt_rn(sa.aa()), __frsqrt_rn(sb.aa())};
     r.ux = f2{sa.d.x, sb.d.x} * inv; r.uy = f2{sa.d.y, sb.d.y} * inv; r.uz = f2{sa.d.z, sb.d.z} * inv;
 #else
     r.ux = f2{sa.d.x, sb.d.x}; r.uy = f2{sa.d.y, sb.d.y}; r.uz = f2{sa.d.z, sb.d.z};
@@ -421,8 +421,8 @@ CDEV void drain_candidates(CandLists& cl, const SphereLds& lds, int base, const 
             V3 o, d;
             o.x = second ? sb.o.x : sa.o.x; o.y = second ? sb.o.y : sa.o.y; o.z = second ? sb.o.z : sa.o.z;
             d.x = second ? sb.d.x : sa.d.x; d.y = second ? sb.d.y : sa.d.y; d.z = second ? sb.d.z : sa.d.z;
-            const float aa = second ? sb.aa : sa.aa;
-            const float tmin = second ? sb.tmin : sa.tmin;
+            const float aa = second ? sb.aa() : sa.aa();
+            const float tmin = second ? sb.tmin() : sa.tmin();
             float t;
             if (candidate_root(lds.exact[k], o, d, aa, tmin, t)) {
                 // selects on values, not on which variable to update: the four stay in registers
@@ -569,7 +569,7 @@ CDEV RayHalves ray_halves(const Slot& s, const float3 ref, float scale)
     RayHalves r;
     const float qx = (s.o.x - ref.x) * scale, qy = (s.o.y - ref.y) * scale, qz = (s.o.z - ref.z) * scale;
 #if CASTER_STRICT
-    const float inv = __frsqrt_rn(s.aa);
+    const float inv = __frsqrt_rn(s.aa());
     const float ux = s.d.x * inv, uy = s.d.y * inv, uz = s.d.z * inv;
 #else
     const float ux = s.d.x, uy = s.d.y, uz = s.d.z;
@@ -584,7 +584,7 @@ CDEV RayHalves ray_halves(const Slot& s, const float3 ref, float scale)
     // A slot without a path, or a non-finite ray (non_finite_rule decides for it): never a
     // candidate.  A ray so far out that its features leave half-precision range: a candidate for
     // every sphere (the queue code then runs the exact test on all of them).
-    const bool never = !s.alive || !r.finite;
+    const bool never = !s.alive() || !r.finite;
     const float tneg = -thr * (1.0f / kThrScale);           // three halves of it go against kThrScale in the sphere operand
     const bool all = !never && !(big < 60000.0f && __builtin_fabsf(tneg) < 60000.0f);
     _Float16 h[9], l[9];
@@ -719,8 +719,8 @@ CDEV void drain_mfma(MfmaQueue& q, const SceneView& sc, const float4* lds_exact,
             const float bx = fetch(owner, sb.d.x), by = fetch(owner, sb.d.y), bz = fetch(owner, sb.d.z);
             d.x = second ? bx : ax; d.y = second ? by : ay; d.z = second ? bz : az;
         }
-        const float aa_a = fetch(owner, sa.aa), aa_b = fetch(owner, sb.aa);
-        const float tm_a = fetch(owner, sa.tmin), tm_b = fetch(owner, sb.tmin);
+        const float aa_a = fetch(owner, sa.aa()), aa_b = fetch(owner, sb.aa());
+        const float tm_a = fetch(owner, sa.tmin()), tm_b = fetch(owner, sb.tmin());
         const float aa = second ? aa_b : aa_a;
         const float tmin = second ? tm_b : tm_a;
         unsigned long long* dst = q.result + (second ? 64 : 0) + owner;
@@ -850,8 +850,8 @@ CDEV void test_always(const AlwaysLds* al, int n_always, const Slot& sa, const S
         const int index = al->index[h];
         const float4 e = al->exact[h];
         float t;
-        if (candidate_root(e, sa.o, sa.d, sa.aa, sa.tmin, t)) take_hit(t, index, closestA, bestA);
-        if (candidate_root(e, sb.o, sb.d, sb.aa, sb.tmin, t)) take_hit(t, index, closestB, bestB);
+        if (candidate_root(e, sa.o, sa.d, sa.aa(), sa.tmin(), t)) take_hit(t, index, closestA, bestA);
+        if (candidate_root(e, sb.o, sb.d, sb.aa(), sb.tmin(), t)) take_hit(t, index, closestB, bestB);
     }
 }
 
@@ -883,7 +883,7 @@ CDEV bool resolve_hit(const Slot& s, const Ray& r, float closest, int best_sph, 
     int best_rect = -1;
     for (int k = 0; k < sc.n_rect; ++k) {
         float t;
-        if (rect_root(sc.rect_a[k], sc.rect_b[k], r, s.tmin, closest, t)) {
+        if (rect_root(sc.rect_a[k], sc.rect_b[k], r, s.tmin(), closest, t)) {
             const int ord = sc.rect_meta[k].x;
             if (t < closest || ord > best_ord || best_ord < 0) { closest = t; best_ord = ord; best_rect = k; }
         }
@@ -926,7 +926,7 @@ template <bool TEX>
 CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, const TileGeom& tg, acc_t* wave_acc,
                  const RenderArgs& a, unsigned int& rays)
 {
-    if (!s.alive) return;
+    if (!s.alive()) return;
     CASTER_STAT(6);
     rays++;
     Ray r;
@@ -954,6 +954,201 @@ CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, cons
     }
 }
 
+// ---- primary rays ----------------------------------------------------------
+// The camera rays of a work unit all leave the lens disk and pass through the same 8x8-pixel patch
+// of the focus plane (src/camera.c:32-42): a thin beam, which only a handful of the scene's spheres
+// can touch.  They do not go through the all-pairs sphere loop.  When a wave takes a unit it bounds
+// the beam once and notes the spheres the beam can touch in a list in LDS (build_tile_list: a
+// superset, by the argument there); the unit's paths are then started 64 at a time, all lanes busy
+// (primary_batch): camera ray, the reference's root arithmetic (candidate_root) on the directly
+// tested spheres and on the list, closest hit by take_hit's rule, and the first bounce.  What the
+// exact test decides is what it decides in the sphere loop -- a sphere off the list cannot be hit,
+// so leaving it out changes nothing -- and the frames are bit-identical to tracing the camera rays
+// through the loop.  Paths that survive their first bounce wait in a ring of the wave in device
+// memory (PathRing) until a slot of the main loop is free; the loop itself only ever traces rays
+// from the second on, about two thirds of all rays in the benchmark scene.
+constexpr int kTileListCap = 256;           // spheres on a tile's list; beyond that the batch tests all spheres
+
+struct TileList {
+    unsigned short* idx;    // this wave's [kTileListCap] in LDS
+    int count;              // wave-uniform
+    bool all;               // no usable bound (degenerate frame or camera, list overflow): every sphere is tested
+};
+
+CDEV int lane_rank(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Every camera ray of the unit runs from a point a of the lens disk, |a - a0| <= rho_l around the
+// camera position a0, through a point b of the tile's patch of the focus plane, |b - b0| <= rho_q
+// around the patch centre b0: x(s) = a + s (b - a), and s is the ray parameter t of the reference
+// (its direction is b - a, unnormalised), so s > 0.  Against the axis x0(s) = a0 + s (b0 - a0):
+// |x(s) - x0(s)| <= f(s) = |1 - s| rho_l + s rho_q.  A sphere (c, r) touched at parameter s therefore
+// has |x0(s) - c| <= r + f(s).  With z and dperp the axial and the perpendicular coordinate of c and
+// L = |b0 - a0|, that needs |s L - z| <= r + f(s) <= (r + rho_l) + s (rho_l + rho_q), which confines
+// s to [s_lo, s_hi] (empty: the sphere lies behind the lens), and dperp <= r + max f over that
+// interval; f is convex, so the maximum sits at an end.  Every quantity is inflated by 1e-3 of its
+// size and 1e-5 of the distances involved: orders of magnitude more than the rounding of this test
+// or of the reference's, so a sphere the reference's arithmetic would report is on the list.  The
+// test is written as "not provably out of reach", so a sphere with NaN data stays on the list.
+CDEV void build_tile_list(TileList& tl, const Unit& un, const RenderArgs& a, const Cam& cam, const SceneView& sc, int lane)
+{
+    tl.count = 0;
+    tl.all = true;
+    if (a.width < 2 || a.height < 2) return;                     // the pixel coordinates divide by zero: no beam to speak of
+    const float iw = __builtin_amdgcn_rcpf((float)(a.width - 1)), ih = __builtin_amdgcn_rcpf((float)(a.height - 1));
+    const float hu = 0.5f * (float)un.tg.tw * iw, hv = 0.5f * (float)un.tg.th * ih;
+    const float uc = (float)un.tg.x0 * iw + hu, vc = (float)un.tg.y0 * ih + hv;
+    const V3 ax = (cam.llc + (cam.h * uc + cam.v * vc)) - cam.o;
+    const float L = __builtin_amdgcn_sqrtf(dot(ax, ax));
+    const float rho_q = (hu * __builtin_amdgcn_sqrtf(dot(cam.h, cam.h)) + hv * __builtin_amdgcn_sqrtf(dot(cam.v, cam.v))) * 1.002f;
+    const float rho_l = __builtin_fabsf(cam.lr) * 1.002f *
+                        __builtin_amdgcn_sqrtf(__builtin_fmaxf(dot(cam.u0, cam.u0), dot(cam.v0, cam.v0)) + __builtin_fabsf(dot(cam.u0, cam.v0)));
+    const float kk = rho_l + rho_q;
+    if (!(L - kk > 1.0e-3f * L) || !(L < 1.0e30f)) return;       // a beam as wide as it is long, or no finite axis
+    const float inv_l = __builtin_amdgcn_rcpf(L);
+    const V3 e = ax * inv_l;
+    const float inv_lo = __builtin_amdgcn_rcpf(L + kk) * 0.999f, inv_hi = __builtin_amdgcn_rcpf(L - kk) * 1.001f;
+    tl.all = false;
+    for (int base = 0; base < sc.n_sph; base += 64) {
+        const int k = base + lane;
+        bool cand = false;
+        if (k < sc.n_sph) {
+            const float4 sp = sc.sph[k];
+            const V3 v = mk(sp.x, sp.y, sp.z) - cam.o;
+            const float z = dot(v, e);
+            const V3 w = v - e * z;
+            const float dperp = __builtin_amdgcn_sqrtf(dot(w, w));
+            const float r = __builtin_fabsf(sp.w);
+            const float slack = 1.0e-5f * ((__builtin_fabsf(z) + dperp) + L);
+            const float R0 = (r + rho_l) * 1.001f + slack;
+            const float s_hi = (z + R0) * inv_hi;                                // only looked at when z + R0 >= 0
+            const float s_lo = __builtin_fmaxf((z - R0) * inv_lo, 0.0f);
+            const float f_lo = __builtin_fabsf(1.0f - s_lo) * rho_l + s_lo * rho_q;
+            const float f_hi = __builtin_fabsf(1.0f - s_hi) * rho_l + s_hi * rho_q;
+            const float bound = (r + __builtin_fmaxf(f_lo, f_hi)) * 1.001f + slack;
+            const bool out = (z + R0 < 0.0f) || (dperp > bound);
+            cand = !out;
+            for (int h = 0; h < a.scene.n_always; ++h) cand = cand && (k != a.scene.always[h]);   // tested directly
+        }
+        const unsigned long long m = __ballot(cand);
+        if (cand) {
+            const int pos = tl.count + lane_rank(m);
+            if (pos < kTileListCap) tl.idx[pos] = (unsigned short)k;
+        }
+        tl.count += __popcll(m);
+    }
+    if (tl.count > kTileListCap || sc.n_sph > 65535) tl.all = true;
+    // the list is read back by all lanes of this wave; LDS instructions of one wave complete in order
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Paths waiting for a slot: kRingEntries states of this wave in device memory, word-major (the lanes
+// of a push or a pop touch consecutive addresses).  head and count are the same in all lanes.  A
+// state is written and read by different lanes of the same wave: the fences order the two.
+struct PathRing {
+    uint32_t* mem;
+    int head, count;
+};
+
+// The words of a slot's state, in ring order (kRingWords of them at most).
+template <typename F>
+CDEV void for_each_word(Slot& s, F f)
+{
+    int w = 0;
+    auto fl = [&](float& x) { uint32_t u = __float_as_uint(x); f(w++, u); x = __uint_as_float(u); };
+    auto in = [&](int& x) { uint32_t u = (uint32_t)x; f(w++, u); x = (int)u; };
+    fl(s.o.x); fl(s.o.y); fl(s.o.z); fl(s.d.x); fl(s.d.y); fl(s.d.z);
+#if CASTER_STRICT
+    fl(s.aa_);
+#else
+    fl(s.tmin_); fl(s.tmax_);
+#endif
+    fl(s.thr.x); fl(s.thr.y); fl(s.thr.z);
+    f(w++, s.g.s0); f(w++, s.g.s1); f(w++, s.g.s2); f(w++, s.g.s3);
+    in(s.q); in(s.depth);
+}
+
+CDEV void ring_push(PathRing& r, Slot& s)
+{
+    const unsigned long long m = __ballot(s.alive());
+    if (m != 0ull) {
+        if (s.alive()) {
+            uint32_t* p = r.mem + ((r.head + r.count + lane_rank(m)) & (kRingEntries - 1));
+            for_each_word(s, [&](int w, uint32_t& u) { p[w * kRingEntries] = u; });
+        }
+        r.count += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
+// The free lanes of a slot take the oldest waiting paths, in lane order.
+CDEV void ring_pop(PathRing& r, Slot& s)
+{
+    if (r.count == 0) return;                                   // wave-uniform
+    const unsigned long long want = __ballot(!s.alive());
+    if (want == 0ull) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int rank = lane_rank(want);
+    if (!s.alive() && rank < r.count) {
+        CASTER_STAT(11);
+        const uint32_t* p = r.mem + ((r.head + rank) & (kRingEntries - 1));
+        for_each_word(s, [&](int w, uint32_t& u) { u = p[w * kRingEntries]; });
+        s.g.draws = 0;
+    }
+    int n = __popcll(want);
+    if (n > r.count) n = r.count;
+    r.head = (r.head + n) & (kRingEntries - 1);
+    r.count -= n;
+}
+
+// Starts the next 64 paths of the unit (fewer at the end of its pool), traces their camera rays and
+// shades the first hit; the survivors join the ring.  A camera ray with a non-finite component is
+// handled as everywhere else (non_finite_rule).
+template <bool TEX, bool EXACT_LDS>
+CDEV void primary_batch(Unit& cur, const TileList& tl, PathRing& ring, const RenderArgs& a, const Cam& cam, const PixelScale& ps,
+                        const SceneView& sc, const float4* lds_exact, const AlwaysLds* al, acc_t* wave_acc, unsigned int& rays,
+                        int lane)
+{
+    Slot sp;
+    sp.thr = mk(1.0f, 1.0f, 1.0f);
+    sp.g.s0 = sp.g.s1 = sp.g.s2 = sp.g.s3 = sp.g.draws = 0;
+    sp.q = 0; sp.depth = 0;
+    park(sp);
+    const int m = cur.next + lane;
+    if (m < cur.total) { CASTER_STAT(13); start_pool_path(sp, m, cur, a, cam, ps); }
+    cur.next = (cur.next + 64 < cur.total) ? cur.next + 64 : cur.total;
+    float closest = sp.tmax();                    // a root equal to tmax is still accepted
+    int best = -1;
+    for (int h = 0; h < a.scene.n_always; ++h) {
+        float t;
+        if (candidate_root(al->exact[h], sp.o, sp.d, sp.aa(), sp.tmin(), t)) take_hit(t, al->index[h], closest, best);
+    }
+    const int n = tl.all ? sc.n_sph : tl.count;
+    for (int i = 0; i < n; ++i) {
+        int k = i;
+        if (tl.all) {
+            bool direct = false;
+            for (int h = 0; h < a.scene.n_always; ++h) direct |= (a.scene.always[h] == i);
+            if (direct) continue;
+        } else {
+            k = __builtin_amdgcn_readfirstlane((int)tl.idx[i]);
+        }
+        const float4 ex = EXACT_LDS ? lds_exact[k] : exact_image(sc.sph[k]);
+        float t;
+        if (candidate_root(ex, sp.o, sp.d, sp.aa(), sp.tmin(), t)) take_hit(t, k, closest, best);
+    }
+    const bool finite = __builtin_isfinite(sp.o.x) && __builtin_isfinite(sp.o.y) && __builtin_isfinite(sp.o.z) &&
+                        __builtin_isfinite(sp.d.x) && __builtin_isfinite(sp.d.y) && __builtin_isfinite(sp.d.z);
+    non_finite_rule(finite, sc.n_sph, closest, best);
+    bounce<TEX>(sp, closest, best, sc, cur.tg, wave_acc, a, rays);
+    ring_push(ring, sp);
+    ring.head = __builtin_amdgcn_readfirstlane(ring.head);
+    ring.count = __builtin_amdgcn_readfirstlane(ring.count);
+}
+
 CDEV void swap_slots(Slot& a, Slot& b)
 {
     Slot t = a;
@@ -973,7 +1168,8 @@ CDEV void swap_slots(Slot& a, Slot& b)
 constexpr int lds_fixed_bytes(int kind)
 {
     return (int)sizeof(unsigned long long) * kWaves * kAccStride +
-           kWaves * (kind >= kLoopMatrix ? kMfmaQueueBytes : 2 * kListCap * 64);
+           kWaves * (kind >= kLoopMatrix ? kMfmaQueueBytes : 2 * kListCap * 64) +
+           kWaves * kTileListCap * (int)sizeof(unsigned short);
 }
 
 template <int KIND, bool TEX>
@@ -986,10 +1182,12 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     extern __shared__ __align__(16) unsigned char s_dyn[];
     __shared__ AlwaysLds s_always;
     // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists (u16; [kWaves][kListCap][64], or
-    // the results and the queues of MfmaQueue for the matrix loop), the exact sphere image of one tile, the noise tables
+    // the results and the queues of MfmaQueue for the matrix loop), the tile lists of the camera rays
+    // (u16 [kWaves][kTileListCap]), the exact sphere image of one tile, the noise tables
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
     unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * kAccStride);
     float4* s_exact = reinterpret_cast<float4*>(s_dyn + lds_fixed_bytes(KIND));
+    unsigned short* s_tile = reinterpret_cast<unsigned short*>(s_dyn + lds_fixed_bytes(KIND)) - kWaves * kTileListCap;
     float4* s_noise_vec = s_exact + a.lds_spheres;                              // only if the scene has noise tables
 
     SceneView sc = view_of(a.scene);
@@ -1048,40 +1246,73 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     cur.tg.x0 = cur.tg.y0 = cur.tg.tw = cur.tg.th = 0;
     bool queue_empty = false;
 
+    // Camera rays are traced apart from the loop (see "primary rays"); paths enter the slots with their
+    // second ray, from the ring.
+    constexpr bool kExactLds = KIND == kLoopVector || KIND == kLoopMatrix;      // the whole scene's exact image sits in LDS
+    PathRing ring;
+    ring.mem = a.ring + (size_t)(blockIdx.x * kWaves + (unsigned)wave) * (size_t)(kRingEntries * kRingWords);
+    ring.head = 0;
+    ring.count = 0;
+    TileList tl;
+    tl.idx = s_tile + wave * kTileListCap;
+    tl.count = 0;
+    tl.all = true;
+    unsigned int batches = 0;                   // wave-uniform
+
     for (;;) {
         // The per-slot code is written once and the slots trade places after each turn; the two
         // turns are unrolled, so the trade costs nothing (as a loop it was 30 register moves per
         // turn: 1 % of the frame).  Both copies come from the same source, and the tests hold a path
-        // to the same bits in either slot, in both arithmetic modes.  The unit is
-        // changed between a slot's bounce and its refill: when the pool ran dry in the first slot's
-        // refill, the second slot already draws on the next unit in the same trip.
+        // to the same bits in either slot, in both arithmetic modes.
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const unsigned long long t_bounce = tm.now();
             bounce<TEX>(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
             tm.add(WaveTimers::kBounce, t_bounce);
-            const unsigned long long t_sched = tm.now();
-            if (cur.chunk >= 0 && cur.next >= cur.total) {
-                flush_unit(cur, wave_acc, a, lane);
-                cur.chunk = -1;
-                cur.tg.tw = cur.tg.th = 0;      // no current tile
-            }
-            if (cur.chunk < 0 && !queue_empty) {
-                cur = fetch_unit(a, tiles_x, n_tiles, lane);
-                queue_empty = cur.chunk < 0;
-                tm.fetched(!queue_empty, cur.chunk, cur.tg.x0 / kTileW, cur.tg.y0 / kTileH);
-            }
-            tm.add(WaveTimers::kSchedule, t_sched);
-            const unsigned long long t_refill = tm.now();
-            refill(sa, cur, a, cam, ps);
-            tm.add(WaveTimers::kRefill, t_refill);
             swap_slots(sa, sb);
             float tf = closestA; closestA = closestB; closestB = tf;
             int ti = bestA; bestA = bestB; bestB = ti;
         }
+        // Supply: the free slots take waiting paths from the ring; before that, as long as the ring
+        // holds fewer than they want, the current unit starts another batch of paths.  A round serves
+        // up to 64 slots (a batch adds up to 64 paths and the ring holds 128); a tile whose paths all
+        // end on the same bounce frees more than that at once, and the rounds repeat.  A unit whose
+        // pool is empty hands its sums to the frame buffer and the wave takes the next one; its paths
+        // still waiting or in flight add their radiance to the frame buffer themselves when they end
+        // (deposit).
+        {
+            const unsigned long long t_refill = tm.now();
+            for (;;) {
+                const int need = __popcll(__ballot(!sa.alive())) + __popcll(__ballot(!sb.alive()));
+                if (need == 0) break;
+                const int want = need < 64 ? need : 64;
+                while (ring.count < want) {
+                    if (cur.chunk >= 0 && cur.next >= cur.total) {
+                        flush_unit(cur, wave_acc, a, lane);
+                        cur.chunk = -1;
+                        cur.tg.tw = cur.tg.th = 0;      // no current tile
+                    }
+                    if (cur.chunk < 0) {
+                        if (queue_empty) break;
+                        cur = fetch_unit(a, tiles_x, n_tiles, lane);
+                        queue_empty = cur.chunk < 0;
+                        tm.fetched(!queue_empty, cur.chunk, cur.tg.x0 / kTileW, cur.tg.y0 / kTileH);
+                        if (queue_empty) break;
+                        build_tile_list(tl, cur, a, cam, sc, lane);
+                    }
+                    primary_batch<TEX, kExactLds>(cur, tl, ring, a, cam, ps, sc, s_exact, &s_always, wave_acc, rays, lane);
+                    ++batches;
+                }
+                if (ring.count == 0) break;             // nothing left to start
+                ring_pop(ring, sa);
+                ring_pop(ring, sb);
+                if (need <= 64) break;
+            }
+            tm.add(WaveTimers::kRefill, t_refill);
+        }
 
-        const int live = (sa.alive || sb.alive) ? 1 : 0;
-        const bool done = queue_empty && cur.chunk < 0;
+        const int live = (sa.alive() || sb.alive()) ? 1 : 0;
+        const bool done = queue_empty && cur.chunk < 0 && ring.count == 0;
         if (TILED) {
             // the tile loop below has block-wide barriers: all four waves leave together
             if (__syncthreads_or((live || !done) ? 1 : 0) == 0) break;
@@ -1110,7 +1341,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         tm.trip();
         ++trips;
         const unsigned long long t_isect = tm.now();
-        closestA = sa.tmax; closestB = sb.tmax;     // a root equal to tmax is still accepted
+        closestA = sa.tmax(); closestB = sb.tmax();     // a root equal to tmax is still accepted
         bestA = bestB = -1;
         test_always(&s_always, a.scene.n_always, sa, sb, closestA, closestB, bestA, bestB);
         if (MATRIX) {
@@ -1144,6 +1375,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
     if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
     if (lane == 0 && trips) atomicAdd(a.trips, (unsigned long long)trips);
+    if (lane == 0 && batches) atomicAdd(a.batches, (unsigned long long)batches);
     tm.report(wave, __shfl(wrays, 0, 64));
 }
 
@@ -1170,6 +1402,7 @@ hipError_t CASTER_NAME(launch_render_)(const RenderArgs& a_in, int resident_bloc
     // resident_blocks counts CASTER_BLOCKS_PER_CU per CU
     if (kind >= kLoopMatrix) resident_blocks = resident_blocks / CASTER_BLOCKS_PER_CU * CASTER_MATRIX_BLOCKS_PER_CU;
     if (blocks > resident_blocks) blocks = resident_blocks;      // persistent: the waves loop over the queue
+    if (!a.ring || blocks * kWaves > a.ring_waves) return hipErrorInvalidValue;     // every wave needs its ring
     const dim3 grid((unsigned)blocks), block(kBlock);
     // A scene whose every texture is a solid colour runs instances without the texture code (the
     // benchmark's case).  The choice depends on the scene alone, never on the loop: the two loops of a
@@ -1221,13 +1454,13 @@ void CASTER_NAME(k_test_trace_)(SceneDev sd, int n, const float* ray6, int32_t* 
             rr[k].o = mk(q[0], q[1], q[2]);
             rr[k].d = mk(q[3], q[4], q[5]);
             set_ray(sl[k], rr[k]);
-            sl[k].alive = true;
+            sl[k].depth = 1;
 #if !CASTER_STRICT
-            len[k] = sl[k].tmin / kTMin;
+            len[k] = sl[k].tmin() / kTMin;
 #endif
         }
     }
-    float closest[2] = {sl[0].tmax, sl[1].tmax};
+    float closest[2] = {sl[0].tmax(), sl[1].tmax()};
     int best[2] = {-1, -1};
     const PairRays pr = pack_rays(sl[0], sl[1], ref);
     CandLists cl;
@@ -1328,7 +1561,7 @@ CDEV void audit_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, int b
     V3 o, d;
     o.x = fetch(owner, s.o.x); o.y = fetch(owner, s.o.y); o.z = fetch(owner, s.o.z);
     d.x = fetch(owner, s.d.x); d.y = fetch(owner, s.d.y); d.z = fetch(owner, s.d.z);
-    const float aa = fetch(owner, s.aa), tmin = fetch(owner, s.tmin);
+    const float aa = fetch(owner, s.aa()), tmin = fetch(owner, s.tmin());
     const float oo = fetch(owner, oo_scaled);
     const bool ok = fetch(owner, valid ? 1.0f : 0.0f) != 0.0f;
     const int ray = (CB >> 1) * 64 + owner;
@@ -1371,7 +1604,7 @@ void CASTER_NAME(k_filter_audit_)(SceneDev sd, int n, const float* ray6, uint32_
             r.o = mk(q[0], q[1], q[2]);
             r.d = mk(q[3], q[4], q[5]);
             set_ray(sl[k], r);
-            sl[k].alive = true;
+            sl[k].depth = 1;
         }
     }
     const bool matrix = sd.mfma_blocks > 0 && sc.mfma_tab != nullptr;
@@ -1383,7 +1616,7 @@ void CASTER_NAME(k_filter_audit_)(SceneDev sd, int n, const float* ray6, uint32_
                         qz = (sl[k].o.z - ref.z) * sd.mfma_scale;
             oo[k] = qx * qx + qy * qy + qz * qz;
         }
-        const bool validA = sl[0].alive && mr.finiteA, validB = sl[1].alive && mr.finiteB;
+        const bool validA = sl[0].alive() && mr.finiteA, validB = sl[1].alive() && mr.finiteB;
         const uint4* tab = sc.mfma_tab + lane;
 #pragma unroll 1
         for (int blk = 0; blk < sd.mfma_blocks; ++blk) {
@@ -1408,9 +1641,9 @@ void CASTER_NAME(k_filter_audit_)(SceneDev sd, int n, const float* ray6, uint32_
             const float cx = sp.x - ref.x, cy = sp.y - ref.y, cz = sp.z - ref.z;
             const float cc = (cx * cx + cy * cy + cz * cz) + sp.w * sp.w;
             float t;
-            if (sl[0].alive && pr.finiteA && candidate_root(exact_image(sp), sl[0].o, sl[0].d, sl[0].aa, sl[0].tmin, t))
+            if (sl[0].alive() && pr.finiteA && candidate_root(exact_image(sp), sl[0].o, sl[0].d, sl[0].aa(), sl[0].tmin(), t))
                 audit_note(&s_audit, wave, lane, key.x >= pr.thrA, (key.x - pr.thrA) / (oo.x + cc));
-            if (sl[1].alive && pr.finiteB && candidate_root(exact_image(sp), sl[1].o, sl[1].d, sl[1].aa, sl[1].tmin, t))
+            if (sl[1].alive() && pr.finiteB && candidate_root(exact_image(sp), sl[1].o, sl[1].d, sl[1].aa(), sl[1].tmin(), t))
                 audit_note(&s_audit, wave, 64 + lane, key.y >= pr.thrB, (key.y - pr.thrB) / (oo.y + cc));
         }
     }

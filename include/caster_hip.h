@@ -184,6 +184,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
  * overlap on one GPU (two streams, two contexts, two threads) race; calls in stream order do not,
  * each clears what it needs.  caster_hip_render_stats / _info afterwards report this call. */
 #define CASTER_HIP_NOALLOC_MAX_PIXELS (1u << 20)
+#define CASTER_HIP_NOALLOC_MAX_WAVES 4096u
 int caster_hip_render_noalloc(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height,
                               int sample_begin, int sample_count, int max_depth,
                               uint32_t seed, uint32_t flags, float* accum_dev);
@@ -207,6 +208,7 @@ typedef struct {
     float kernel_ms;
     uint64_t rays;
     uint64_t wave_trips;
+    uint64_t primary_batches;
 } caster_render_info;
 int caster_hip_render_info(caster_hip_ctx* ctx, caster_render_info* out);
 

@@ -83,5 +83,5 @@ for mode in args.modes.split(","):
         flops = rays * (18 * ns + 12 * nr + 100)
         print(f"{mode:6s} rep{rep} rays {rays} ({rays / (args.width * args.height * args.spp):.2f}/path) kernel {ms:.2f} ms wall {wall * 1e3:.2f} ms "
               f"{rays / ms * 1e-3:.1f} Mrays/s  {flops / (ms * 1e-3) / 157.3e12 * 100:.1f}% of FP32 peak (algorithmic)  "
-              f"loop {info['loop']} blocks {info['mfma_blocks']} trips {info['wave_trips']}", flush=True)
+              f"loop {info['loop']} blocks {info['mfma_blocks']} trips {info['wave_trips']} batches {info.get('primary_batches', 0)}", flush=True)
 gpu.free(acc)
