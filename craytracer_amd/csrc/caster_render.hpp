@@ -926,9 +926,11 @@ template <bool TEX>
 CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, const TileGeom& tg, acc_t* wave_acc,
                  const RenderArgs& a, unsigned int& rays)
 {
+    const unsigned long long tracing = __ballot(s.alive());
+    if (tracing == 0ull) return;
+    rays += (unsigned int)__popcll(tracing);     // counted per wave: the same in all lanes
     if (!s.alive()) return;
     CASTER_STAT(6);
-    rays++;
     Ray r;
     r.o = s.o;
     r.d = s.d;
@@ -967,7 +969,7 @@ CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, cons
 // through the loop.  Paths that survive their first bounce wait in a ring of the wave in device
 // memory (PathRing) until a slot of the main loop is free; the loop itself only ever traces rays
 // from the second on, about two thirds of all rays in the benchmark scene.
-constexpr int kTileListCap = 256;           // spheres on a tile's list; beyond that the batch tests all spheres
+constexpr int kTileListCap = 128;           // spheres on a tile's list; beyond that the batch tests all spheres
 
 struct TileList {
     unsigned short* idx;    // this wave's [kTileListCap] in LDS
@@ -1045,6 +1047,17 @@ CDEV void build_tile_list(TileList& tl, const Unit& un, const RenderArgs& a, con
     __builtin_amdgcn_wave_barrier();
 }
 
+// Between two bounces a slot's throughput and pixel are of no use to the sphere loop, where registers
+// are scarcest: the main loop keeps them in LDS (one float4 per slot and lane) and has them in
+// registers only while the slot bounces.
+CDEV void cold_out(const Slot& s, float4* home) { *home = make_float4(s.thr.x, s.thr.y, s.thr.z, __int_as_float(s.q)); }
+CDEV void cold_in(Slot& s, const float4* home)
+{
+    const float4 v = *home;
+    s.thr = mk(v.x, v.y, v.z);
+    s.q = __float_as_int(v.w);
+}
+
 // Paths waiting for a slot: kRingEntries states of this wave in device memory, word-major (the lanes
 // of a push or a pop touch consecutive addresses).  head and count are the same in all lanes.  A
 // state is written and read by different lanes of the same wave: the fences order the two.
@@ -1085,7 +1098,7 @@ CDEV void ring_push(PathRing& r, Slot& s)
 }
 
 // The free lanes of a slot take the oldest waiting paths, in lane order.
-CDEV void ring_pop(PathRing& r, Slot& s)
+CDEV void ring_pop(PathRing& r, Slot& s, float4* home)
 {
     if (r.count == 0) return;                                   // wave-uniform
     const unsigned long long want = __ballot(!s.alive());
@@ -1097,6 +1110,7 @@ CDEV void ring_pop(PathRing& r, Slot& s)
         const uint32_t* p = r.mem + ((r.head + rank) & (kRingEntries - 1));
         for_each_word(s, [&](int w, uint32_t& u) { u = p[w * kRingEntries]; });
         s.g.draws = 0;
+        cold_out(s, home);
     }
     int n = __popcll(want);
     if (n > r.count) n = r.count;
@@ -1149,13 +1163,6 @@ CDEV void primary_batch(Unit& cur, const TileList& tl, PathRing& ring, const Ren
     ring.count = __builtin_amdgcn_readfirstlane(ring.count);
 }
 
-CDEV void swap_slots(Slot& a, Slot& b)
-{
-    Slot t = a;
-    a = b;
-    b = t;
-}
-
 // Resident blocks per CU = waves per SIMD.  Measured on the 1080p benchmark (strict, ms per frame):
 // 3 (168 VGPRs, no spills) 291, 4 (128 VGPRs) 276, 5 (96 VGPRs) 290, 6 (80 VGPRs) 314.
 #ifndef CASTER_BLOCKS_PER_CU
@@ -1169,7 +1176,8 @@ constexpr int lds_fixed_bytes(int kind)
 {
     return (int)sizeof(unsigned long long) * kWaves * kAccStride +
            kWaves * (kind >= kLoopMatrix ? kMfmaQueueBytes : 2 * kListCap * 64) +
-           kWaves * kTileListCap * (int)sizeof(unsigned short);
+           kWaves * kTileListCap * (int)sizeof(unsigned short) +
+           kWaves * 2 * 64 * (int)sizeof(float4);
 }
 
 template <int KIND, bool TEX>
@@ -1183,11 +1191,13 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     __shared__ AlwaysLds s_always;
     // layout: accumulators [kWaves][kAccStride] (acc_t), candidate lists (u16; [kWaves][kListCap][64], or
     // the results and the queues of MfmaQueue for the matrix loop), the tile lists of the camera rays
-    // (u16 [kWaves][kTileListCap]), the exact sphere image of one tile, the noise tables
+    // (u16 [kWaves][kTileListCap]), the slots' throughput and pixel between bounces (cold_out), the exact
+    // sphere image of one tile, the noise tables
     acc_t* s_acc = reinterpret_cast<acc_t*>(s_dyn);
     unsigned short* s_cand = reinterpret_cast<unsigned short*>(s_acc + kWaves * kAccStride);
     float4* s_exact = reinterpret_cast<float4*>(s_dyn + lds_fixed_bytes(KIND));
-    unsigned short* s_tile = reinterpret_cast<unsigned short*>(s_dyn + lds_fixed_bytes(KIND)) - kWaves * kTileListCap;
+    float4* s_cold = reinterpret_cast<float4*>(s_dyn + lds_fixed_bytes(KIND)) - kWaves * 2 * 64;       // [kWaves][2 slots][64 lanes]
+    unsigned short* s_tile = reinterpret_cast<unsigned short*>(s_cold) - kWaves * kTileListCap;
     float4* s_noise_vec = s_exact + a.lds_spheres;                              // only if the scene has noise tables
 
     SceneView sc = view_of(a.scene);
@@ -1221,9 +1231,6 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     park(sb);
     unsigned int rays = 0;
     unsigned int trips = 0;                     // wave-uniform
-    float closestA = kTMax, closestB = kTMax;
-    int bestA = -1, bestB = -1;
-
     CandLists cl;
     cl.mem = s_cand + wave * kListCap * 64 + lane;
     cl.cnt = 0;
@@ -1258,21 +1265,12 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     tl.count = 0;
     tl.all = true;
     unsigned int batches = 0;                   // wave-uniform
+    float4* homeA = s_cold + wave * 128 + lane;
+    float4* homeB = homeA + 64;
+    cold_out(sa, homeA);
+    cold_out(sb, homeB);
 
     for (;;) {
-        // The per-slot code is written once and the slots trade places after each turn; the two
-        // turns are unrolled, so the trade costs nothing (as a loop it was 30 register moves per
-        // turn: 1 % of the frame).  Both copies come from the same source, and the tests hold a path
-        // to the same bits in either slot, in both arithmetic modes.
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const unsigned long long t_bounce = tm.now();
-            bounce<TEX>(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
-            tm.add(WaveTimers::kBounce, t_bounce);
-            swap_slots(sa, sb);
-            float tf = closestA; closestA = closestB; closestB = tf;
-            int ti = bestA; bestA = bestB; bestB = ti;
-        }
         // Supply: the free slots take waiting paths from the ring; before that, as long as the ring
         // holds fewer than they want, the current unit starts another batch of paths.  A round serves
         // up to 64 slots (a batch adds up to 64 paths and the ring holds 128); a tile whose paths all
@@ -1304,8 +1302,8 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
                     ++batches;
                 }
                 if (ring.count == 0) break;             // nothing left to start
-                ring_pop(ring, sa);
-                ring_pop(ring, sb);
+                ring_pop(ring, sa, homeA);
+                ring_pop(ring, sb, homeB);
                 if (need <= 64) break;
             }
             tm.add(WaveTimers::kRefill, t_refill);
@@ -1319,8 +1317,6 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         } else {
             if (__any(live) == 0) {
                 if (done) break;
-                closestA = closestB = kTMax;
-                bestA = bestB = -1;
                 continue;           // nothing to trace; units still have to be retired or fetched
             }
         }
@@ -1341,42 +1337,51 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         tm.trip();
         ++trips;
         const unsigned long long t_isect = tm.now();
-        closestA = sa.tmax(); closestB = sb.tmax();     // a root equal to tmax is still accepted
-        bestA = bestB = -1;
+        float closestA = sa.tmax(), closestB = sb.tmax();       // a root equal to tmax is still accepted
+        int bestA = -1, bestB = -1;
         test_always(&s_always, a.scene.n_always, sa, sb, closestA, closestB, bestA, bestB);
         if (MATRIX) {
             const MfmaRays mr = pack_rays_mfma(sa, sb, ref, a.scene.mfma_scale);
             isect_mfma<KIND == kLoopMatrix>(sc, s_exact, a.scene.mfma_blocks, mr, ml, sa, sb, closestA, closestB, bestA, bestB, tm);
             non_finite_rule(mr.finiteA, sc.n_sph, closestA, bestA);
             non_finite_rule(mr.finiteB, sc.n_sph, closestB, bestB);
-            tm.add(WaveTimers::kIntersect, t_isect);
-            continue;
-        }
-        const PairRays pr = pack_rays(sa, sb, ref);
-        if (!TILED) {
-            isect_tile(lds, n_lds, 0, pr, cl, sa, sb, closestA, closestB, bestA, bestB, tm);
         } else {
-            for (int base = 0; base < sc.n_sph; base += kSphTile) {
-                const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
-                if (base) __syncthreads();           // everyone is done with the previous tile
-                const int padded = stage_spheres(s_exact, sc, base, cnt);
-                lds.count = cnt;
-                __syncthreads();
-                isect_tile(lds, padded, base, pr, cl, sa, sb, closestA, closestB, bestA, bestB, tm);
+            const PairRays pr = pack_rays(sa, sb, ref);
+            if (!TILED) {
+                isect_tile(lds, n_lds, 0, pr, cl, sa, sb, closestA, closestB, bestA, bestB, tm);
+            } else {
+                for (int base = 0; base < sc.n_sph; base += kSphTile) {
+                    const int cnt = (sc.n_sph - base < kSphTile) ? sc.n_sph - base : kSphTile;
+                    if (base) __syncthreads();           // everyone is done with the previous tile
+                    const int padded = stage_spheres(s_exact, sc, base, cnt);
+                    lds.count = cnt;
+                    __syncthreads();
+                    isect_tile(lds, padded, base, pr, cl, sa, sb, closestA, closestB, bestA, bestB, tm);
+                }
             }
+            non_finite_rule(pr.finiteA, sc.n_sph, closestA, bestA);
+            non_finite_rule(pr.finiteB, sc.n_sph, closestB, bestB);
         }
-        non_finite_rule(pr.finiteA, sc.n_sph, closestA, bestA);
-        non_finite_rule(pr.finiteB, sc.n_sph, closestB, bestB);
         tm.add(WaveTimers::kIntersect, t_isect);
+
+        // Both slots bounce.  The code is the same for the two (one source, two inlined copies), and
+        // the tests hold a path to the same bits in either slot, in both arithmetic modes.
+        const unsigned long long t_bounce = tm.now();
+        cold_in(sa, homeA);
+        bounce<TEX>(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
+        cold_out(sa, homeA);
+        cold_in(sb, homeB);
+        bounce<TEX>(sb, closestB, bestB, sc, cur.tg, wave_acc, a, rays);
+        cold_out(sb, homeB);
+        tm.add(WaveTimers::kBounce, t_bounce);
     }
     tm.add(WaveTimers::kTotal, t_begin);
 
-    unsigned int wrays = rays;
-    for (int off = 32; off > 0; off >>= 1) wrays += __shfl_down(wrays, off, 64);
+    const unsigned int wrays = rays;            // bounce counts for the wave
     if (lane == 0 && wrays) atomicAdd(a.rays, (unsigned long long)wrays);
     if (lane == 0 && trips) atomicAdd(a.trips, (unsigned long long)trips);
     if (lane == 0 && batches) atomicAdd(a.batches, (unsigned long long)batches);
-    tm.report(wave, __shfl(wrays, 0, 64));
+    tm.report(wave, wrays);
 }
 
 // Sphere slots of the exact image in LDS: one tile, padded, plus the read-ahead slack.
