@@ -13,6 +13,7 @@ _LIB_DIR = os.path.join(_HERE, "lib")
 
 STRICT = 1
 VECTOR_LOOP = 2      # evaluate the sphere filter on the vector unit (A/B against the matrix cores)
+NO_TILE_LISTS = 4    # camera rays meet every sphere instead of their tile's list (tests)
 
 OBJECT_DTYPE = np.dtype([("type", "<i4"), ("material", "<i4"), ("g", "<f4", (6,))])
 MATERIAL_DTYPE = np.dtype(
@@ -367,12 +368,14 @@ class CasterHip:
         )
 
     # -- the hot path
-    def render(self, cam, width, height, sample_begin, sample_count, max_depth, seed, accum_ptr: int, strict=False, vector_loop=False):
+    def render(self, cam, width, height, sample_begin, sample_count, max_depth, seed, accum_ptr: int, strict=False, vector_loop=False,
+               tile_lists=True):
         cam = _f32(cam, (19,))
         _check(
             self._lib.caster_hip_render(
                 self._ctx, _ptr(cam), C.c_int(width), C.c_int(height), C.c_int(sample_begin), C.c_int(sample_count),
-                C.c_int(max_depth), C.c_uint32(seed), C.c_uint32((STRICT if strict else 0) | (VECTOR_LOOP if vector_loop else 0)), C.c_void_p(accum_ptr),
+                C.c_int(max_depth), C.c_uint32(seed),
+                C.c_uint32((STRICT if strict else 0) | (VECTOR_LOOP if vector_loop else 0) | (0 if tile_lists else NO_TILE_LISTS)), C.c_void_p(accum_ptr),
             ),
             "caster_hip_render",
         )
@@ -415,13 +418,14 @@ class CasterHip:
             "caster_hip_resolve_dev",
         )
 
-    def render_image(self, cam, width, height, spp, max_depth, seed, strict=False, sample_begin=0, vector_loop=False):
+    def render_image(self, cam, width, height, spp, max_depth, seed, strict=False, sample_begin=0, vector_loop=False, tile_lists=True):
         """Convenience: allocate, render, return (sums [h, w, 4] float32 with j = 0 at the bottom, rays, kernel ms)."""
         nbytes = width * height * 16
         acc = self.malloc(nbytes)
         try:
             self.memset_zero(acc, nbytes)
-            self.render(cam, width, height, sample_begin, spp, max_depth, seed, acc, strict=strict, vector_loop=vector_loop)
+            self.render(cam, width, height, sample_begin, spp, max_depth, seed, acc, strict=strict, vector_loop=vector_loop,
+                        tile_lists=tile_lists)
             rays, ms = self.render_stats()
             sums = self.download(acc, (height, width, 4), np.float32)
         finally:

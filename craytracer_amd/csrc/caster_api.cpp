@@ -615,6 +615,7 @@ static int render_on(caster_hip_ctx* ctx, const caster_camera* cam, int width, i
     a.batches = counters + 3;
     a.ring = ring;
     a.ring_waves = ring_waves;
+    a.tile_lists = (flags & CASTER_HIP_NO_TILE_LISTS) ? 0 : 1;
     a.n_units = 0;
     a.lds_spheres = 0;
     const int strict = (flags & CASTER_HIP_STRICT) ? 1 : 0;
@@ -639,7 +640,7 @@ static int check_render_args(caster_hip_ctx* ctx, const caster_camera* cam, int 
     if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
         return fail(CASTER_HIP_ERR_ARG, "frame size %dx%d out of range", width, height);
     if (sample_begin < 0 || sample_count < 0) return fail(CASTER_HIP_ERR_ARG, "negative sample range");
-    if ((flags & ~(uint32_t)(CASTER_HIP_STRICT | CASTER_HIP_VECTOR_LOOP)) != 0)
+    if ((flags & ~(uint32_t)(CASTER_HIP_STRICT | CASTER_HIP_VECTOR_LOOP | CASTER_HIP_NO_TILE_LISTS)) != 0)
         return fail(CASTER_HIP_ERR_ARG, "unknown flag bits 0x%x", flags);
     return CASTER_HIP_OK;
 }

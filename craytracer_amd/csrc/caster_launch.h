@@ -90,6 +90,7 @@ struct RenderArgs {
     unsigned long long* batches; // batches of 64 camera rays traced against their tile's sphere list, zero at launch
     uint32_t* ring;          // kRingBytesPerWave bytes for every wave of the launch; contents need no initialisation
     int ring_waves;          // waves the ring buffer has room for
+    int tile_lists;          // 0: camera rays meet every sphere (CASTER_HIP_NO_TILE_LISTS)
     int n_units;             // filled in by the launcher
     int lds_spheres;         // float4 slots per sphere image in LDS (filled in by the launcher)
 };

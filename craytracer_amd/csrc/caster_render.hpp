@@ -344,16 +344,13 @@ CDEV f2 candidate_key(const PairRays& r, const float4 f /* c'x, c'y, g*scale - K
 // root beyond the closest hit is rejected there together with the second root, which is
 // never smaller.  So the closest hit is a minimum over (t, later-sphere-first) and can be taken
 // in any order.
-CDEV bool candidate_root(const float4 e /* cx, cy, r*r, cz */, V3 o, V3 d, float aa, float tmin, float& t)
+// Second half of candidate_root: from oc.d (hb), oc.oc - r*r (c) and the discriminant to the root.
+CDEV bool root_tail(float hb, float c, float disc, float aa, float tmin, float& t)
 {
-    const float ocx = o.x - e.x, ocy = o.y - e.y, ocz = o.z - e.w;
 #if CASTER_STRICT
     // The reference's arithmetic, operation for operation.  One early return that cannot change
     // its outcome: hb >= 0 and c >= 0 give sqrt_d <= hb (sqrt(fl(hb*hb)) == hb exactly and the
     // discriminant is not larger), so both numerators are <= 0 and both roots are below tmin > 0.
-    const float hb = (ocx * d.x + ocy * d.y) + ocz * d.z;
-    const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - e.z;
-    const float disc = hb * hb - aa * c;
     if (disc < 0.0f) return false;
     if (hb >= 0.0f && c >= 0.0f) return false;
     const float sq = sqrtf(disc);
@@ -366,9 +363,6 @@ CDEV bool candidate_root(const float4 e /* cx, cy, r*r, cz */, V3 o, V3 d, float
     return true;
 #else
     (void)aa;   // the direction has unit length
-    const float hb = fmaf(ocz, d.z, fmaf(ocy, d.y, ocx * d.x));
-    const float c = fmaf(ocz, ocz, fmaf(ocy, ocy, fmaf(ocx, ocx, -e.z)));
-    const float disc = fmaf(hb, hb, -c);
     if (!(disc >= 0.0f && (hb < 0.0f || c < 0.0f))) return false;
     const float sq = __builtin_amdgcn_sqrtf(disc);
     float root = -hb - sq;
@@ -377,6 +371,21 @@ CDEV bool candidate_root(const float4 e /* cx, cy, r*r, cz */, V3 o, V3 d, float
     t = root;
     return true;
 #endif
+}
+
+CDEV bool candidate_root(const float4 e /* cx, cy, r*r, cz */, V3 o, V3 d, float aa, float tmin, float& t)
+{
+    const float ocx = o.x - e.x, ocy = o.y - e.y, ocz = o.z - e.w;
+#if CASTER_STRICT
+    const float hb = (ocx * d.x + ocy * d.y) + ocz * d.z;
+    const float c = ((ocx * ocx + ocy * ocy) + ocz * ocz) - e.z;
+    const float disc = hb * hb - aa * c;
+#else
+    const float hb = fmaf(ocz, d.z, fmaf(ocy, d.y, ocx * d.x));
+    const float c = fmaf(ocz, ocz, fmaf(ocy, ocy, fmaf(ocx, ocx, -e.z)));
+    const float disc = fmaf(hb, hb, -c);
+#endif
+    return root_tail(hb, c, disc, aa, tmin, t);
 }
 
 // Takes the hit at t on sphere `index` if it beats what the slot has: the reference's in-order
@@ -554,57 +563,33 @@ constexpr float kFilterMarginMfma = kFilterMarginFast + kFilterMarginMfmaExtra;
 
 struct RayHalves {
     h8 f00, f01, f10, f11;      // slots 0-7, 8-15, 16-23, 24-31
-    bool finite;
 };
 constexpr float kThrScale = 1024.0f;    // the threshold enters the product as (threshold / kThrScale) * kThrScale: keeps it in half-precision range
 
-CDEV void split_half(float x, _Float16& hi, _Float16& lo)
-{
-    hi = (_Float16)x;
-    lo = (_Float16)(x - (float)hi);
-}
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// Two floats to two halves (round to nearest even), in one register: v_cvt_pk_f16_f32.
+CDEV unsigned int halves(float lo, float hi) { return __builtin_bit_cast(unsigned int, __builtin_convertvector(f2{lo, hi}, h2)); }
+CDEV float low_half(unsigned int pair) { return (float)__builtin_bit_cast(h2, pair).x; }
+CDEV float high_half(unsigned int pair) { return (float)__builtin_bit_cast(h2, pair).y; }
 
-CDEV RayHalves ray_halves(const Slot& s, const float3 ref, float scale)
+// The 32 k-slots of one ray from its nine features f (already zero for a ray that is never, or
+// always, a candidate) and the three pieces of its threshold.  Feature k takes slots 3k (its upper
+// half h, against the sphere's upper half), 3k + 1 (the rest l = f - h, against the upper half) and
+// 3k + 2 (h again, against the sphere's rest); slots 27, 28 hold 1 (against the two halves of the
+// sphere's constant), 29-31 the threshold.  Pairs of slots that sit in one register are converted
+// together.
+CDEV RayHalves split_features(const float (&f)[9], float t0, float t1, float t2)
 {
+    const unsigned int h01 = halves(f[0], f[1]), h23 = halves(f[2], f[3]), h45 = halves(f[4], f[5]),
+                       h67 = halves(f[6], f[7]), h8o = halves(f[8], 1.0f);
+    const float r0 = f[0] - low_half(h01), r1 = f[1] - high_half(h01), r2 = f[2] - low_half(h23),
+                r3 = f[3] - high_half(h23), r4 = f[4] - low_half(h45), r5 = f[5] - high_half(h45),
+                r6 = f[6] - low_half(h67), r7 = f[7] - high_half(h67), r8 = f[8] - low_half(h8o);
     RayHalves r;
-    const float qx = (s.o.x - ref.x) * scale, qy = (s.o.y - ref.y) * scale, qz = (s.o.z - ref.z) * scale;
-#if CASTER_STRICT
-    const float inv = __frsqrt_rn(s.aa());
-    const float ux = s.d.x * inv, uy = s.d.y * inv, uz = s.d.z * inv;
-#else
-    const float ux = s.d.x, uy = s.d.y, uz = s.d.z;
-#endif
-    const float oo = qx * qx + qy * qy + qz * qz;
-    const float od = qx * ux + qy * uy + qz * uz;
-    const float wx = qx - od * ux, wy = qy - od * uy, wz = qz - od * uz;
-    const float thr = (wx * wx + wy * wy + wz * wz) - oo * kFilterMarginMfma;
-    r.finite = (thr - thr == 0.0f);
-    float f[9] = {ux * ux, uy * uy, uz * uz, 2.0f * ux * uy, 2.0f * ux * uz, 2.0f * uy * uz, wx + wx, wy + wy, wz + wz};
-    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f[6]), __builtin_fabsf(f[7])), __builtin_fabsf(f[8]));
-    // A slot without a path, or a non-finite ray (non_finite_rule decides for it): never a
-    // candidate.  A ray so far out that its features leave half-precision range: a candidate for
-    // every sphere (the queue code then runs the exact test on all of them).
-    const bool never = !s.alive() || !r.finite;
-    const float tneg = -thr * (1.0f / kThrScale);           // three halves of it go against kThrScale in the sphere operand
-    const bool all = !never && !(big < 60000.0f && __builtin_fabsf(tneg) < 60000.0f);
-    _Float16 h[9], l[9];
-    _Float16 t0 = (_Float16)tneg;
-    _Float16 t1 = (_Float16)(tneg - (float)t0);
-    _Float16 t2 = (_Float16)((tneg - (float)t0) - (float)t1);
-    if (never || all) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) f[k] = 0.0f;
-        // the key is then the sphere's constant alone (at most 65504 in size) plus 3 * 60000 * kThrScale of either sign
-        t0 = t1 = t2 = (_Float16)(never ? -60000.0f : 60000.0f);
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) split_half(f[k], h[k], l[k]);
-    const _Float16 one = (_Float16)1.0f;
-    // slot 3f: hi (against the sphere's hi), 3f+1: lo (against hi), 3f+2: hi (against lo)
-    r.f00 = h8{h[0], l[0], h[0], h[1], l[1], h[1], h[2], l[2]};
-    r.f01 = h8{h[2], h[3], l[3], h[3], h[4], l[4], h[4], h[5]};
-    r.f10 = h8{l[5], h[5], h[6], l[6], h[6], h[7], l[7], h[7]};
-    r.f11 = h8{h[8], l[8], h[8], one, one, t0, t1, t2};
+    r.f00 = __builtin_bit_cast(h8, make_uint4(halves(f[0], r0), h01, halves(r1, f[1]), halves(f[2], r2)));
+    r.f01 = __builtin_bit_cast(h8, make_uint4(h23, halves(r3, f[3]), halves(f[4], r4), h45));
+    r.f10 = __builtin_bit_cast(h8, make_uint4(halves(r5, f[5]), halves(f[6], r6), h67, halves(r7, f[7])));
+    r.f11 = __builtin_bit_cast(h8, make_uint4(halves(f[8], r8), h8o, halves(1.0f, t0), halves(t1, t2)));
     return r;
 }
 
@@ -629,12 +614,49 @@ struct MfmaRays {
     bool finiteA, finiteB;
 };
 
+// The filter's ray operand of one slot: features, threshold, k-slots.  (Scalar FP32 on purpose: with
+// packed operations in the kernel that holds the matrix instructions this toolchain has produced
+// code that misses candidates, differently from run to run.)
+CDEV RayHalves ray_halves(const Slot& s, const float3 ref, float scale, bool& finite)
+{
+    const float qx = (s.o.x - ref.x) * scale, qy = (s.o.y - ref.y) * scale, qz = (s.o.z - ref.z) * scale;
+#if CASTER_STRICT
+    const float inv = __frsqrt_rn(s.aa());
+    const float ux = s.d.x * inv, uy = s.d.y * inv, uz = s.d.z * inv;
+#else
+    const float ux = s.d.x, uy = s.d.y, uz = s.d.z;
+#endif
+    const float oo = qx * qx + qy * qy + qz * qz;
+    const float od = qx * ux + qy * uy + qz * uz;
+    const float wx = qx - od * ux, wy = qy - od * uy, wz = qz - od * uz;
+    const float thr = (wx * wx + wy * wy + wz * wz) - oo * kFilterMarginMfma;
+    finite = (thr - thr == 0.0f);
+    float f[9] = {ux * ux, uy * uy, uz * uz, 2.0f * ux * uy, 2.0f * ux * uz, 2.0f * uy * uz, wx + wx, wy + wy, wz + wz};
+    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(f[6]), __builtin_fabsf(f[7])), __builtin_fabsf(f[8]));
+    // A slot without a path, or a non-finite ray (non_finite_rule decides for it): never a
+    // candidate.  A ray so far out that its features leave half-precision range: a candidate for
+    // every sphere (the queue code then runs the exact test on all of them).
+    const bool never = !s.alive() || !finite;
+    const float tn = -thr * (1.0f / kThrScale);             // three halves of it go against kThrScale in the sphere operand
+    const bool all = !never && !(big < 60000.0f && __builtin_fabsf(tn) < 60000.0f);
+    // the threshold in three halves: t0 + t1 + t2
+    const float r1 = tn - (float)(_Float16)tn;
+    const float r2 = r1 - (float)(_Float16)r1;
+    float t0 = tn, t1 = r1, t2 = r2;
+    if (never || all) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) f[i] = 0.0f;
+        // the key is then the sphere's constant alone (at most 65504 in size) plus 3 * 60000 * kThrScale of either sign
+        t0 = t1 = t2 = never ? -60000.0f : 60000.0f;
+    }
+    return split_features(f, t0, t1, t2);
+}
+
 CDEV MfmaRays pack_rays_mfma(const Slot& sa, const Slot& sb, const float3 ref, float scale)
 {
-    RayHalves ra = ray_halves(sa, ref, scale);
-    RayHalves rb = ray_halves(sb, ref, scale);
     MfmaRays m;
-    m.finiteA = ra.finite; m.finiteB = rb.finite;
+    RayHalves ra = ray_halves(sa, ref, scale, m.finiteA);
+    RayHalves rb = ray_halves(sb, ref, scale, m.finiteB);
     swap_halves(ra.f00, ra.f01); swap_halves(ra.f10, ra.f11);
     swap_halves(rb.f00, rb.f01); swap_halves(rb.f10, rb.f11);
     m.b00 = ra.f00; m.b10 = ra.f01; m.b01 = ra.f10; m.b11 = ra.f11;
@@ -998,6 +1020,7 @@ CDEV void build_tile_list(TileList& tl, const Unit& un, const RenderArgs& a, con
 {
     tl.count = 0;
     tl.all = true;
+    if (!a.tile_lists) return;
     if (a.width < 2 || a.height < 2) return;                     // the pixel coordinates divide by zero: no beam to speak of
     const float iw = __builtin_amdgcn_rcpf((float)(a.width - 1)), ih = __builtin_amdgcn_rcpf((float)(a.height - 1));
     const float hu = 0.5f * (float)un.tg.tw * iw, hv = 0.5f * (float)un.tg.th * ih;
@@ -1150,6 +1173,7 @@ CDEV void primary_batch(Unit& cur, const TileList& tl, PathRing& ring, const Ren
         } else {
             k = __builtin_amdgcn_readfirstlane((int)tl.idx[i]);
         }
+        CASTER_STAT(14);
         const float4 ex = EXACT_LDS ? lds_exact[k] : exact_image(sc.sph[k]);
         float t;
         if (candidate_root(ex, sp.o, sp.d, sp.aa(), sp.tmin(), t)) take_hit(t, k, closest, best);

@@ -42,7 +42,12 @@ enum {
     /* Evaluate the conservative sphere filter on the vector unit even where the scene qualifies
      * for the matrix cores.  Both forms hand the same candidates' exact tests to the same code, so
      * the results are identical; the flag exists for scenes' A/B timing and for the tests. */
-    CASTER_HIP_VECTOR_LOOP = 2u
+    CASTER_HIP_VECTOR_LOOP = 2u,
+    /* Camera rays are traced against a short list of spheres per 8x8-pixel tile: the spheres the
+     * tile's beam of camera rays (lens disk to the tile's patch of the focus plane) can touch, by a
+     * conservative bound.  With this flag every camera ray meets every sphere instead.  The results
+     * are identical; the flag exists so that the tests can hold the two against each other. */
+    CASTER_HIP_NO_TILE_LISTS = 4u
 };
 
 /* Object, material and texture tags: inc/caster.h:71-75, inc/material.h:17-20,32-35. */

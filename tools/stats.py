@@ -21,7 +21,7 @@ import craytracer_amd as ca  # noqa: E402
 
 NAMES = {0: "trips", 1: "drain iterations", 2: "accept A", 3: "accept B", 4: "unit-sphere loop iterations",
          5: "disk loop iterations", 6: "bounce executions", 7: "lambertian", 8: "metal", 9: "dielectric", 10: "light",
-         11: "path starts", 12: "candidate events", 13: "candidate lanes"}
+         11: "ring pops", 12: "candidate events", 13: "camera-ray batches", 14: "tile-list spheres tested"}
 lib = b.load_caster_lib()
 gpu = ca.CasterHip(0)
 def opt(name, default):
