@@ -973,9 +973,9 @@ int caster_hip_test_texture(caster_hip_ctx* ctx, uint32_t flags, int n, const in
     return CASTER_HIP_OK;
 }
 
-int caster_hip_test_rng(caster_hip_ctx* ctx, uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24)
+int caster_hip_test_rng(caster_hip_ctx* ctx, uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out23)
 {
-    if (!ctx || !out24) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
+    if (!ctx || !out23) return fail(CASTER_HIP_ERR_ARG, "NULL argument");
     if (n < 0) return fail(CASTER_HIP_ERR_ARG, "n < 0");
     if (n == 0) return CASTER_HIP_OK;
     DeviceGuard guard(ctx->device);
@@ -983,7 +983,7 @@ int caster_hip_test_rng(caster_hip_ctx* ctx, uint32_t seed, uint32_t pixel, uint
     HIP_TRY(d.alloc(sizeof(uint32_t) * n));
     HIP_TRY(caster::launch_test_rng(seed, pixel, sample, n, d.as<uint32_t>(), ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(d.get(out24, sizeof(uint32_t) * n));
+    HIP_TRY(d.get(out23, sizeof(uint32_t) * n));
     return CASTER_HIP_OK;
 }
 

@@ -170,12 +170,14 @@ CDEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y + a.z * b.z); }      
 CDEV V3 to_unit(V3 v) { return v / sqrtf(dot(v, v)); }                          // common.c:89-97
 
 // ------------------------------------------------------------------ RNG --
-// Replaces rand() (src/common.c:10-13).  One xoshiro128+ stream per path: the
-// four state words are a chain of 32-bit avalanche hashes of (seed, pixel,
-// sample); a draw is the top 24 bits of the output, random_f32 = n / 2^24.
-// A draw costs eight full-rate integer ops and no multiply, which matters
-// because the rejection samplers make the wave pay for its slowest lane.
-struct Rng { uint32_t s0, s1, s2, s3; uint32_t draws; };
+// Replaces rand() (src/common.c:10-13).  One stream per path: the 64-bit xoroshiro engine (two
+// 32-bit words; s1 ^= s0, s0 = rotl(s0, 26) ^ s1 ^ (s1 << 9), s1 = rotl(s1, 13)) with the sum of the
+// two words as output, seeded by two chained 32-bit avalanche hashes of (seed, pixel, sample).  A
+// draw is the top 23 bits of the output, random_f32 = n / 2^23: exact in binary32, never 1.  A draw
+// costs six full-rate integer operations and two to make the float, and no multiply -- which
+// matters because the rejection samplers make the wave pay for its slowest lane -- and a path
+// carries two state words.
+struct Rng { uint32_t s0, s1; uint32_t draws; };
 
 CDEV uint32_t mix32(uint32_t x)
 {
@@ -191,33 +193,36 @@ CDEV void rng_seed(Rng& g, uint32_t seed, uint32_t pixel, uint32_t sample)
 {
     const uint32_t a = mix32(pixel ^ mix32(seed + 0x9E3779B9u));
     const uint32_t b = mix32(sample + a);
-    const uint32_t c = mix32(b + 0x9E3779B9u);
-    const uint32_t d = mix32(c + 0x9E3779B9u);
-    g.s0 = a; g.s1 = b; g.s2 = c; g.s3 = d | 1u;
+    g.s0 = a; g.s1 = b | 1u;            // never the all-zero state
     g.draws = 0;
 }
 
 CDEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 
-// One xoshiro128+ step: s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= s1 << 9; s3 = rotl(s3, 11),
-// written with three-input xors (one instruction each) so that a draw is eight integer operations.
-CDEV uint32_t rng_next24(Rng& g)
+// One step; returns the 32-bit output.
+CDEV uint32_t rng_step(Rng& g)
 {
-    const uint32_t result = g.s0 + g.s3;
-    const uint32_t t = g.s1 << 9;
-    const uint32_t n1 = xor3(g.s1, g.s2, g.s0);
-    const uint32_t n0 = xor3(g.s0, g.s3, g.s1);
-    const uint32_t n2 = xor3(g.s2, g.s0, t);
-    const uint32_t x3 = g.s3 ^ g.s1;
-    g.s0 = n0; g.s1 = n1; g.s2 = n2;
-    g.s3 = (x3 << 11) | (x3 >> 21);
-    return result >> 8;
+    const uint32_t result = g.s0 + g.s1;
+    const uint32_t x = g.s1 ^ g.s0;
+    g.s0 = xor3(__builtin_amdgcn_alignbit(g.s0, g.s0, 6u), x, x << 9);     // rotl(s0, 26) ^ x ^ (x << 9)
+    g.s1 = __builtin_amdgcn_alignbit(x, x, 19u);                           // rotl(x, 13)
+    return result;
+}
+
+// The integer of a draw: the top 23 bits of the output.
+CDEV uint32_t rng_next23(Rng& g) { return rng_step(g) >> 9; }
+
+// 1 + n / 2^23 for the next draw n: the 23 bits dropped into the mantissa of a float in [1, 2)
+// (one v_alignbit_b32: {0x7F : output} >> 9).
+CDEV float rng_one_plus(Rng& g)
+{
+    g.draws++;
+    return __uint_as_float(__builtin_amdgcn_alignbit(0x7Fu, rng_step(g), 9u));
 }
 
 CDEV float random_f32(Rng& g)                                   // common.c:10-13
 {
-    g.draws++;
-    return (float)rng_next24(g) * 5.9604644775390625e-8f;       // n / 2^24, exact
+    return rng_one_plus(g) - 1.0f;                              // n / 2^23, exact
 }
 
 CDEV float random_range_f32(Rng& g, float lo, float hi)         // common.c:15-18
@@ -225,13 +230,12 @@ CDEV float random_range_f32(Rng& g, float lo, float hi)         // common.c:15-1
     return lo + (hi - lo) * random_f32(g);
 }
 
-// random_range_f32(g, -1, 1) in one rounding step: n / 2^24 and its double are exact, so
-// -1 + 2 * (n / 2^24) rounds once, and so does fma(n, 2^-23, -1): the same bits, two operations
-// fewer in loops where the wave pays for its slowest lane.
+// random_range_f32(g, -1, 1) = -1 + 2 * (n / 2^23) (common.c:15-18): every step of it is exact, and
+// so is 2 * (1 + n / 2^23) - 3 in one fused operation: the same bits, fewer operations in loops where
+// the wave pays for its slowest lane.
 CDEV float random_pm1(Rng& g)
 {
-    g.draws++;
-    return __builtin_fmaf((float)rng_next24(g), 1.1920928955078125e-7f, -1.0f);
+    return __builtin_fmaf(rng_one_plus(g), 2.0f, -3.0f);
 }
 
 CDEV V3 random_unit_sphere(Rng& g)                              // common.c:108-126

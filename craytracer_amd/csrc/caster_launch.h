@@ -70,7 +70,7 @@ constexpr int kMaxChunks = 256;
 // Paths between their first and their second ray wait in a ring of the wave in device memory (see
 // "primary rays" in caster_render.hpp): kRingEntries path states of kRingWords 32-bit words, word-major.
 constexpr int kRingEntries = 128;
-constexpr int kRingWords = 17;
+constexpr int kRingWords = 15;
 constexpr size_t kRingBytesPerWave = (size_t)kRingEntries * kRingWords * sizeof(uint32_t);
 constexpr int kWavesPerBlock = 4;
 
@@ -131,6 +131,6 @@ CASTER_DECLARE_LAUNCHERS(fast)
 hipError_t launch_fold(const unsigned long long* fixed, int n_pixels, int sample_count, float4* accum, hipStream_t st);
 hipError_t launch_add(float* dst, const float* src, size_t n, hipStream_t st);
 hipError_t launch_resolve(const float4* accum, int width, int height, int spp, uint8_t* rgba, hipStream_t st);
-hipError_t launch_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24, hipStream_t st);
+hipError_t launch_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out23, hipStream_t st);
 
 }  // namespace caster

@@ -1103,7 +1103,7 @@ CDEV void for_each_word(Slot& s, F f)
     fl(s.tmin_); fl(s.tmax_);
 #endif
     fl(s.thr.x); fl(s.thr.y); fl(s.thr.z);
-    f(w++, s.g.s0); f(w++, s.g.s1); f(w++, s.g.s2); f(w++, s.g.s3);
+    f(w++, s.g.s0); f(w++, s.g.s1);
     in(s.q); in(s.depth);
 }
 
@@ -1151,7 +1151,7 @@ CDEV void primary_batch(Unit& cur, const TileList& tl, PathRing& ring, const Ren
 {
     Slot sp;
     sp.thr = mk(1.0f, 1.0f, 1.0f);
-    sp.g.s0 = sp.g.s1 = sp.g.s2 = sp.g.s3 = sp.g.draws = 0;
+    sp.g.s0 = sp.g.s1 = sp.g.draws = 0;
     sp.q = 0; sp.depth = 0;
     park(sp);
     const int m = cur.next + lane;
@@ -1248,7 +1248,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
 
     Slot sa, sb;
     sa.thr = sb.thr = mk(1.0f, 1.0f, 1.0f);
-    sa.g.s0 = sa.g.s1 = sa.g.s2 = sa.g.s3 = sa.g.draws = 0;
+    sa.g.s0 = sa.g.s1 = sa.g.draws = 0;
     sb.g = sa.g;
     sa.q = sb.q = 0; sa.depth = sb.depth = 0;
     park(sa);

@@ -47,12 +47,12 @@ __global__ void k_resolve(const float4* accum, int width, int height, int spp, u
     reinterpret_cast<uchar4*>(rgba)[(size_t)y * width + x] = o;
 }
 
-__global__ void k_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24)
+__global__ void k_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out23)
 {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     Rng g;
     rng_seed(g, seed, pixel, sample);
-    for (int k = 0; k < n; ++k) out24[k] = rng_next24(g);
+    for (int k = 0; k < n; ++k) out23[k] = rng_next23(g);
 }
 
 hipError_t launch_fold(const unsigned long long* fixed, int n_pixels, int sample_count, float4* accum, hipStream_t st)
@@ -78,9 +78,9 @@ hipError_t launch_resolve(const float4* accum, int width, int height, int spp, u
     return hipGetLastError();
 }
 
-hipError_t launch_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24, hipStream_t st)
+hipError_t launch_test_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out23, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_test_rng, dim3(1), dim3(64), 0, st, seed, pixel, sample, n, out24);
+    hipLaunchKernelGGL(k_test_rng, dim3(1), dim3(64), 0, st, seed, pixel, sample, n, out23);
     return hipGetLastError();
 }
 

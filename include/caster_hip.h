@@ -284,9 +284,9 @@ int caster_hip_test_math(caster_hip_ctx* ctx, uint32_t flags, int fn, int n, con
  * cores where the scene qualifies, on the vector unit otherwise or with CASTER_HIP_VECTOR_LOOP. */
 int caster_hip_filter_audit(caster_hip_ctx* ctx, uint32_t flags, int n, const float* ray6,
                             uint32_t* accepted, uint32_t* missed, float* slack);
-/* First n 24-bit draws of the stream keyed (seed, pixel, sample). */
+/* First n 23-bit draws of the stream keyed (seed, pixel, sample). */
 int caster_hip_test_rng(caster_hip_ctx* ctx, uint32_t seed, uint32_t pixel, uint32_t sample,
-                        int n, uint32_t* out24);
+                        int n, uint32_t* out23);
 
 #ifdef __cplusplus
 }

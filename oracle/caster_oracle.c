@@ -19,10 +19,11 @@
 /*
  * The reference draws from libc rand() (src/common.c:10-13), seeded from the
  * wall clock, so its images are not reproducible.  Mode ORC_RNG_COUNTER is the
- * replacement the HIP path shares: one xoshiro128+ stream per path, whose four
- * state words are a chain of 32-bit avalanche hashes of (seed, pixel, sample);
- * one draw is the top 24 bits of the generator's output, so
- * random_f32 = n / 2^24 lies in [0, 1) and is exact in binary32.
+ * replacement the HIP path shares: one stream per path on the 64-bit xoroshiro
+ * engine (two 32-bit words) with the sum of the words as output, seeded by two
+ * chained 32-bit avalanche hashes of (seed, pixel, sample); one draw is the top
+ * 23 bits of the output, so random_f32 = n / 2^23 lies in [0, 1) and is exact in
+ * binary32.
  */
 static uint32_t orc_mix32(uint32_t x)
 {
@@ -38,32 +39,28 @@ void orc_rng_seed(orng* g, uint32_t seed, uint32_t pixel, uint32_t sample)
 {
     const uint32_t a = orc_mix32(pixel ^ orc_mix32(seed + 0x9E3779B9u));
     const uint32_t b = orc_mix32(sample + a);
-    const uint32_t c = orc_mix32(b + 0x9E3779B9u);
-    const uint32_t d = orc_mix32(c + 0x9E3779B9u);
-    g->s[0] = a; g->s[1] = b; g->s[2] = c; g->s[3] = d | 1u;
+    g->s[0] = a; g->s[1] = b | 1u;
     g->draws = 0;
     g->mode = ORC_RNG_COUNTER;
 }
 
 void orc_rng_libc(orng* g)
 {
-    g->s[0] = g->s[1] = g->s[2] = g->s[3] = 0;
+    g->s[0] = g->s[1] = 0;
     g->draws = 0;
     g->mode = ORC_RNG_LIBC;
 }
 
-uint32_t orc_rng_next24(orng* g)
+static uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+uint32_t orc_rng_next23(orng* g)
 {
     uint32_t* s = g->s;
-    const uint32_t result = s[0] + s[3];
-    const uint32_t t = s[1] << 9;
-    s[2] ^= s[0];
-    s[3] ^= s[1];
-    s[1] ^= s[2];
-    s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = (s[3] << 11) | (s[3] >> 21);
-    return result >> 8;
+    const uint32_t result = s[0] + s[1];
+    const uint32_t x = s[1] ^ s[0];
+    s[0] = rotl32(s[0], 26) ^ x ^ (x << 9);
+    s[1] = rotl32(x, 13);
+    return result >> 9;
 }
 
 /* src/common.c:10-13 */
@@ -72,7 +69,7 @@ float orc_random_f32(orng* g)
     g->draws++;
     if (g->mode == ORC_RNG_LIBC)
         return rand() / (RAND_MAX + 1.0f);
-    return orc_rng_next24(g) / 16777216.0f;
+    return orc_rng_next23(g) / 8388608.0f;
 }
 
 /* src/common.c:15-18 */
@@ -782,12 +779,12 @@ void orc_batch_texture(const oscene* sc, int n, const int32_t* mat, const float*
     }
 }
 
-void orc_batch_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24)
+void orc_batch_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out23)
 {
     orng g;
     orc_rng_seed(&g, seed, pixel, sample);
     for (int k = 0; k < n; k++)
-        out24[k] = orc_rng_next24(&g);
+        out23[k] = orc_rng_next23(&g);
 }
 
 /* The small vector and optics functions, array at a time (item k reads in8[8k..], writes out3[3k..]):

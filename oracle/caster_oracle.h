@@ -109,7 +109,7 @@ typedef struct {
 
 void     orc_rng_seed(orng* g, uint32_t seed, uint32_t pixel, uint32_t sample);
 void     orc_rng_libc(orng* g);
-uint32_t orc_rng_next24(orng* g);
+uint32_t orc_rng_next23(orng* g);
 
 float orc_random_f32(orng* g);
 float orc_random_range_f32(orng* g, float lo, float hi);
@@ -187,7 +187,7 @@ void orc_batch_camera_ray(const ocam* cam, int n, const float* uv2, uint32_t see
                           float* out_ray6, int32_t* draws);
 void orc_batch_texture(const oscene* sc, int n, const int32_t* mat, const float* uv2, const float* p3,
                        float* rgb3);
-void orc_batch_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out24);
+void orc_batch_rng(uint32_t seed, uint32_t pixel, uint32_t sample, int n, uint32_t* out23);
 void orc_batch_math(int fn, int n, const float* in8, float* out3);
 
 #ifdef __cplusplus

@@ -25,7 +25,7 @@ def images():
 
 def test_rng_golden_and_statistics(orc, vectors):
     assert np.array_equal(orc.rng(0xC0FFEE, 12345, 7, 64), vectors["rng_stream"])
-    x = orc.rng(3, 2, 1, 400000).astype(np.float64) / 2 ** 24
+    x = orc.rng(3, 2, 1, 400000).astype(np.float64) / 2 ** 23
     assert x.min() >= 0 and x.max() < 1           # random_f32 never returns 1.0
     assert abs(x.mean() - 0.5) < 2e-3 and abs(x.var() - 1 / 12) < 1e-3
     assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 5e-3
