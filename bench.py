@@ -281,6 +281,7 @@ def main():
         info = gpu.render_info()               # waits for this rank's frame: the frame boundary
         note("step: frame complete")
         rays_step[0] = info["rays"]
+        info["paths"] = W * H * count          # camera rays of this rank's share: one per path
         info_step[0] = info
         kernel_ms.append(info["kernel_ms"])    # HIP events on the kernel's own stream, around the kernel alone
         spans.append(e)
@@ -336,11 +337,11 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_frame * args.steps / elapsed * 1e-6
         workload = f"rtiow_final_scene {W}x{H} {SPP}spp depth{args.depth}"
-        roof = roofline_of(main_info, main_kernel_ms, args.mode, ns, nr, all_solid)
+        roof = roofline_of(main_info, main_kernel_ms, args.mode, ns, nr, all_solid, main_info["paths"])
         recorded(roof, workload, args.mode, world, main_info["loop"], with_traffic=True)
         if vector_leg is not None:
             v_info, v_ms, v_wall_ms = vector_leg
-            vr = roofline_of(v_info, v_ms, args.mode, ns, nr, all_solid)
+            vr = roofline_of(v_info, v_ms, args.mode, ns, nr, all_solid, v_info["paths"])
             vr["ms_per_frame"] = round(v_wall_ms, 3)
             vr["mrays_per_s"] = round(v_info["rays"] / (v_wall_ms * 1e-3) * 1e-6, 2)
             vr["steps"] = args.vector_steps
@@ -432,7 +433,7 @@ def other_workloads(ca, torch, dev, args, strict):
                     ms.append(info["kernel_ms"])
             kms = float(np.mean(ms))
             all_solid = bool((fs.materials["tex_type"] == 0).all())
-            roof = roofline_of(info, kms, args.mode, fs.n_spheres, fs.n_rects, all_solid)
+            roof = roofline_of(info, kms, args.mode, fs.n_spheres, fs.n_rects, all_solid, w * h * spp)
             roof.pop("note", None)
             out[name] = {
                 "workload": f"{name} {w}x{h} {spp}spp depth{args.depth}", "objects": int(len(fs.objects)), "steps": args.workload_steps,
@@ -445,13 +446,16 @@ def other_workloads(ca, torch, dev, args, strict):
     return out
 
 
-def roofline_of(info, kernel_ms, mode, n_spheres, n_rects, all_solid):
+def roofline_of(info, kernel_ms, mode, n_spheres, n_rects, all_solid, paths=0):
     """Roofline entry of one launch of the render kernel, from what the launch itself reports
     (caster_hip_render_info: which sphere loop ran, wave trips, rays) and its HIP-event duration.
 
     Executed work, so the fraction cannot exceed 1:
       * matrix loop: every wave trip meets 4 blocks of 32 rays with every block of 32 spheres through two
-        v_mfma_f32_32x32x16_f16 -> trips x blocks x 4 x 2 x 32768 flop, against the dense FP16 matrix peak;
+        v_mfma_f32_32x32x16_f16 -> trips x blocks x 4 x 2 x 32768 flop, against the dense FP16 matrix peak.
+        Only rays from a path's second on go through the loop: the camera rays of a tile are traced against
+        the tile's short sphere list in batches of 64 (primary_batches), so a frame executes about a third
+        fewer trips, and matrix flops, than it has rays / 128;
       * vector loop: every trip evaluates the packed filter (1 multiply + 6 FMAs = 13 flop) for 128 ray
         slots and every sphere of the padded list, against the FP32 vector peak.
     The work of the reference's loop as written (18 flop per ray-sphere test) is reported beside it as
@@ -463,8 +467,9 @@ def roofline_of(info, kernel_ms, mode, n_spheres, n_rects, all_solid):
         executed = trips * info["mfma_blocks"] * 4 * 2 * MFMA_FLOPS / sec * 1e-12
         bound, peak, kind = "mfma", F16_MFMA_PEAK_TFLOPS, info["loop_kind"]
         note = ("executed flops of the conservative sphere filter on the matrix cores (f16 operands, f32 accumulate) "
-                "against the dense f16 matrix peak; the kernel as a whole is co-bound by vector-instruction issue "
-                "(exact tests, shading, path starts): see counters")
+                "against the dense f16 matrix peak; camera rays do not go through the filter (per-tile sphere lists), so the "
+                "executed flops cover the rays from a path's second on; the kernel as a whole is bound by vector-instruction "
+                "issue (one instruction per 4 SIMD cycles: see counters.simd_cycles_per_valu_inst)")
     else:
         padded = (n_spheres + 7) // 8 * 8
         executed = trips * 128 * padded * VECTOR_FILTER_FLOPS_PER_PAIR / sec * 1e-12
@@ -482,7 +487,9 @@ def roofline_of(info, kernel_ms, mode, n_spheres, n_rects, all_solid):
         "loop": info["loop"],
         "kernel_ms": round(kernel_ms, 3),
         "wave_trips": int(trips),
-        "slots_in_use": round(info["rays"] / max(1, trips * 128), 4),
+        "primary_batches": int(info.get("primary_batches", 0)),
+        # rays traced by the loop (all but one camera ray per batch lane) over the loop's ray slots
+        "slots_in_use": round(max(0, info["rays"] - paths) / max(1, trips * 128), 4),
         "algorithmic_equivalent": {
             "tflops": round(float(alg), 3), "flops_per_ray": flops_per_ray(n_spheres, n_rects),
             "of_fp32_vector_peak": round(float(alg) / FP32_VALU_PEAK_TFLOPS, 4),

@@ -1081,15 +1081,19 @@ CDEV void cold_in(Slot& s, const float4* home)
     s.q = __float_as_int(v.w);
 }
 
-// Paths waiting for a slot: kRingEntries states of this wave in device memory, word-major (the lanes
-// of a push or a pop touch consecutive addresses).  head and count are the same in all lanes.  A
-// state is written and read by different lanes of the same wave: the fences order the two.
+// Paths waiting for a slot: up to kRingEntries states of this wave in device memory, word-major (the
+// lanes of a push or a pop touch consecutive addresses), kept as a stack: the free slots take the
+// paths started last.  The order in which paths are traced changes no result, and a stack keeps
+// re-using its lowest entries -- a few KB per wave that stay in the L2 cache instead of a ring's
+// whole extent travelling to memory and back.  count is the same in all lanes.  A state is written
+// and read by different lanes of the same wave: the fences order the two.
 struct PathRing {
     uint32_t* mem;
-    int head, count;
+    int count;
 };
 
-// The words of a slot's state, in ring order (kRingWords of them at most).
+// The words of a slot's state, in ring order: 14 in the strict mode, 15 in the fast mode.
+static_assert(kRingWords >= (CASTER_STRICT ? 14 : 15), "a ring entry holds a slot's whole state");
 template <typename F>
 CDEV void for_each_word(Slot& s, F f)
 {
@@ -1112,7 +1116,7 @@ CDEV void ring_push(PathRing& r, Slot& s)
     const unsigned long long m = __ballot(s.alive());
     if (m != 0ull) {
         if (s.alive()) {
-            uint32_t* p = r.mem + ((r.head + r.count + lane_rank(m)) & (kRingEntries - 1));
+            uint32_t* p = r.mem + (r.count + lane_rank(m));
             for_each_word(s, [&](int w, uint32_t& u) { p[w * kRingEntries] = u; });
         }
         r.count += __popcll(m);
@@ -1120,7 +1124,7 @@ CDEV void ring_push(PathRing& r, Slot& s)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
 
-// The free lanes of a slot take the oldest waiting paths, in lane order.
+// The free lanes of a slot take the paths on top of the stack.
 CDEV void ring_pop(PathRing& r, Slot& s, float4* home)
 {
     if (r.count == 0) return;                                   // wave-uniform
@@ -1130,14 +1134,13 @@ CDEV void ring_pop(PathRing& r, Slot& s, float4* home)
     const int rank = lane_rank(want);
     if (!s.alive() && rank < r.count) {
         CASTER_STAT(11);
-        const uint32_t* p = r.mem + ((r.head + rank) & (kRingEntries - 1));
+        const uint32_t* p = r.mem + (r.count - 1 - rank);
         for_each_word(s, [&](int w, uint32_t& u) { u = p[w * kRingEntries]; });
         s.g.draws = 0;
         cold_out(s, home);
     }
     int n = __popcll(want);
     if (n > r.count) n = r.count;
-    r.head = (r.head + n) & (kRingEntries - 1);
     r.count -= n;
 }
 
@@ -1183,7 +1186,6 @@ CDEV void primary_batch(Unit& cur, const TileList& tl, PathRing& ring, const Ren
     non_finite_rule(finite, sc.n_sph, closest, best);
     bounce<TEX>(sp, closest, best, sc, cur.tg, wave_acc, a, rays);
     ring_push(ring, sp);
-    ring.head = __builtin_amdgcn_readfirstlane(ring.head);
     ring.count = __builtin_amdgcn_readfirstlane(ring.count);
 }
 
@@ -1282,7 +1284,6 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     constexpr bool kExactLds = KIND == kLoopVector || KIND == kLoopMatrix;      // the whole scene's exact image sits in LDS
     PathRing ring;
     ring.mem = a.ring + (size_t)(blockIdx.x * kWaves + (unsigned)wave) * (size_t)(kRingEntries * kRingWords);
-    ring.head = 0;
     ring.count = 0;
     TileList tl;
     tl.idx = s_tile + wave * kTileListCap;

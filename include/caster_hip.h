@@ -170,6 +170,16 @@ int caster_hip_reduce(caster_hip_ctx* const* ctxs, float* const* accum_dev, int 
  * sample_count.  Random draws are keyed by (seed, j*width+i, sample), so any
  * split of the sample range over calls or GPUs renders the same paths.
  * Asynchronous: returns once the work is queued on the context's stream.
+ *
+ * Range of the sums.  Within a call a pixel's radiance is summed in 64-bit fixed point (units of
+ * 2^-32; integer adds commute, which makes a frame bit-reproducible) and converted to float once at
+ * the end.  The radiance a finished path contributes (product of the textures' colours along the
+ * path and the emission, src/caster.c:451-477) is clamped to [0, 1e9] per channel on its way in, a
+ * NaN counts as 0, and a channel's sum over the samples of ONE call must stay below 2^32 (4.29e9):
+ * beyond that the integer wraps silently.  The reference would carry an inf or NaN into the pixel
+ * instead (src/dispatcher.c:24-30).  Scenes with emitters brighter than 1e9, or more than 4e9 of
+ * summed radiance per pixel and call, are outside what this entry point represents; split the
+ * sample range over calls for the latter.
  */
 int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, int height,
                       int sample_begin, int sample_count, int max_depth,
@@ -182,10 +192,13 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
  * stream -- neither is allowed ON a capturing stream, and the call has not been exercised there.
  * Same arguments, same result bit for bit, same asynchrony; it calls no hipMalloc/hipFree or any
  * other allocating routine: the scratch that caster_hip_render keeps in buffers it allocates on
- * first use (the per-pixel fixed-point sums of the call, the ray and trip counters, the work
- * queue's head) lives in a static device array of CASTER_HIP_NOALLOC_MAX_PIXELS * 24 + 32 bytes
- * (24 MiB) that every GPU the library runs on holds until the process ends.  Frames of more pixels
- * are refused with CASTER_HIP_ERR_ARG.  All contexts on one GPU share that GPU's array: calls that
+ * first use or with the context (the per-pixel fixed-point sums of the call, the ray and trip
+ * counters, the work queue's head, the rings in which paths wait between their first and their
+ * second ray) lives in a static device array of CASTER_HIP_NOALLOC_MAX_PIXELS * 24 + 32 +
+ * CASTER_HIP_NOALLOC_MAX_WAVES * 7680 bytes (24 MiB + 30 MiB) that every GPU the library runs on holds
+ * until the process ends.  Frames of more pixels are refused with CASTER_HIP_ERR_ARG, and so is a GPU
+ * that runs more than CASTER_HIP_NOALLOC_MAX_WAVES waves of the render kernel at a time (16 per
+ * compute unit: 4 096 on the 256 units of MI355X).  All contexts on one GPU share that GPU's array: calls that
  * overlap on one GPU (two streams, two contexts, two threads) race; calls in stream order do not,
  * each clears what it needs.  caster_hip_render_stats / _info afterwards report this call. */
 #define CASTER_HIP_NOALLOC_MAX_PIXELS (1u << 20)
@@ -205,7 +218,9 @@ int caster_hip_render_stats(caster_hip_ctx* ctx, uint64_t* rays, float* kernel_m
  * LDS in tiles, 2 filter on the matrix cores, 3 the same for lists of more than 512 spheres.
  * wave_trips counts the trips of all waves through the sphere loop: each trip meets 128 ray slots
  * with every sphere of the list (in the matrix loop: mfma_blocks blocks of 32 spheres x 4 blocks of
- * 32 rays x 2 v_mfma_f32_32x32x16_f16). */
+ * 32 rays x 2 v_mfma_f32_32x32x16_f16).  The loop traces a path from its second ray on; the camera
+ * rays are traced in batches of 64 against the sphere list of their 8x8-pixel tile, and
+ * primary_batches counts those batches. */
 typedef struct {
     int32_t loop_kind;
     int32_t mfma_blocks;

@@ -9,7 +9,9 @@ of a pass (the 8 XCDs report separately):
   simd_cycles            GRBM_GUI_ACTIVE (summed over XCDs) x 32 CUs x 4 SIMDs
   valu_issue_busy        SQ_ACTIVE_INST_VALU x 4 / simd_cycles' wave-level equivalent: the share of SIMD cycles in
                          which a vector instruction was being issued (SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD)
-  valu_insts_per_trip    SQ_INSTS_VALU / wave trips
+  valu_insts_per_trip    SQ_INSTS_VALU / wave trips (a trip traces 128 ray slots from the second ray of a path on; the
+                         instructions of the camera-ray batches are in the numerator as well)
+  valu_insts_per_ray     SQ_INSTS_VALU / rays of the launch (wave-level instructions: 64 lanes each)
   active_lane_frac       SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
   fp32_share_of_valu     (ADD + MUL + FMA + TRANS) / SQ_INSTS_VALU
   fp32_executed_tflops   SQ_INSTS_VALU_FLOPS_FP32 x 64 lanes / kernel seconds (an upper bound: lanes masked off count)
@@ -42,7 +44,7 @@ def read_pass_dir(path):
     return dict(tot), sorted(names)
 
 
-def figures(c, kernel_ms, trips):
+def figures(c, kernel_ms, trips, rays=0.0, batches=0.0):
     simd_cycles = c["GRBM_GUI_ACTIVE"] * 32 * 4
     valu = c["SQ_INSTS_VALU"]
     fp32 = c.get("SQ_INSTS_VALU_ADD_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_FMA_F32", 0) + c.get("SQ_INSTS_VALU_TRANS_F32", 0)
@@ -51,6 +53,9 @@ def figures(c, kernel_ms, trips):
         "shader_clock_ghz": round(c["GRBM_GUI_ACTIVE"] / 8 / (kernel_ms * 1e-3) * 1e-9, 3),
         "valu_insts": valu,
         "valu_insts_per_trip": round(valu / trips, 1) if trips else None,
+        "valu_insts_per_ray": round(valu / rays, 3) if rays else None,
+        "rays": rays,
+        "camera_ray_batches": batches,
         "simd_cycles_per_valu_inst": round(simd_cycles / valu, 3),
         "active_lane_frac": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
         "fp32_share_of_valu": round(fp32 / valu, 4),
@@ -83,8 +88,10 @@ def main():
         line = [ln for ln in open(path + "/p1.log") if " kernel " in ln and " trips " in ln][-1]
         kernel_ms = re.search(r"kernel ([0-9.]+) ms", line).group(1)
         trips = re.search(r"trips ([0-9]+)", line).group(1)
+        rays = re.search(r"rays ([0-9]+)", line).group(1)
+        batches = re.search(r"batches ([0-9]+)", line)
         c, names = read_pass_dir(path)
-        fig = figures(c, float(kernel_ms), float(trips))
+        fig = figures(c, float(kernel_ms), float(trips), float(rays), float(batches.group(1)) if batches else 0.0)
         kernels.append({"workload": workload, "arithmetic_mode": mode, "loop": loop, "kernel": names, "kernel_ms": float(kernel_ms),
                         "wave_trips": float(trips), "figures": fig, "raw": c})
         if loop.startswith("matrix") and "hbm_bytes_per_launch" in fig:

@@ -5,6 +5,7 @@ set -e
 tag=$1
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$tag
+rm -rf $O/kt $O/pmc_matrix $O/pmc_vector
 mkdir -p $O
 cd $R
 timeout -k 10 240 python3 bench.py --steps 5 --warmup 1 > $O/bench_strict.json 2> $O/bench_strict.err
