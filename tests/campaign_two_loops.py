@@ -2,7 +2,9 @@
 sphere filter on the matrix cores.  Random scenes -- sphere counts 34 to 4000, extents from 1e-2 to
 1e4 scene units, centres of mass up to 1e5 from the origin, radii over a factor of 25, random
 cameras inside and outside the cloud -- rendered in both arithmetic modes with the filter on the
-matrix cores and on the vector unit; every pair of frames must agree bit for bit."""
+matrix cores and on the vector unit, and once more with every camera ray meeting every sphere
+instead of its tile's list (lenses from a pinhole to half the cloud across, focus planes before, in
+and behind the cloud); all frames of a case must agree bit for bit."""
 import sys
 import os
 
@@ -40,12 +42,19 @@ def main():
         fs, centre, extent, n = random_scene(rng, case)
         gpu.upload_scene(fs)
         eye = centre + rng.normal(size=3) * extent * float(rng.choice([0.3, 1.5, 4.0]))
-        cam = ca.calculate_cam_info(tuple(eye), tuple(centre), (0, 1, 0), 40.0, np.float32(w / h), 0.0, 1.0)
+        # lens from a pinhole to half the cloud's extent across, focus plane before, in and behind the cloud
+        dist = float(np.linalg.norm(eye - centre))
+        aperture = extent * float(rng.choice([0.0, 0.02, 0.5]))
+        focus = max(dist, 1e-6 * extent) * float(rng.choice([0.3, 1.0, 3.0]))
+        cam = ca.calculate_cam_info(tuple(eye), tuple(centre), (0, 1, 0), 40.0, np.float32(w / h), aperture, focus)
         line = f"case {case:2d} n={n:5d} extent={extent:9.3g} |centre|={np.linalg.norm(centre):9.3g}"
         for strict in (True, False):
             m, mr, _ = gpu.render_image(cam, w, h, spp, 20, case, strict=strict)
             v, vr, _ = gpu.render_image(cam, w, h, spp, 20, case, strict=strict, vector_loop=True)
             same = mr == vr and np.array_equal(m, v, equal_nan=True)
+            # the same frame with every camera ray meeting every sphere (no per-tile lists)
+            a, ar, _ = gpu.render_image(cam, w, h, spp, 20, case, strict=strict, tile_lists=False)
+            same = same and mr == ar and np.array_equal(m, a, equal_nan=True)
             bad += 0 if same else 1
             line += f"  {'strict' if strict else 'fast'}: rays {mr} {'==' if same else '!='}"
         print(line, flush=True)
