@@ -531,6 +531,16 @@ def recorded(roof, workload, mode, world, loop, with_traffic):
                     roof["counters"] = entry.get("figures")
                     if with_traffic and entry.get("figures", {}).get("hbm_bytes_per_launch") is not None:
                         roof["traffic"] = entry["figures"]["hbm_bytes_per_launch"]
+                    valu = entry.get("figures", {}).get("valu_insts")
+                    if valu:
+                        # The unit that bounds the kernel: a SIMD issues one vector instruction of a 64-lane wave per 4
+                        # cycles.  Instructions of this workload's launch (recorded counter, same sources) over this
+                        # run's kernel time, against 1 024 SIMDs at the 2.4 GHz peak clock; under load the part runs
+                        # at about 2.2 GHz and a few instructions issue in fewer than 4 cycles.
+                        peak = 256 * 4 * 2.4e9 / 4.0
+                        rate = valu / (roof["kernel_ms"] * 1e-3)
+                        roof["valu_issue"] = {"bound": "vector-instruction issue", "achieved": round(rate * 1e-9, 2), "peak": round(peak * 1e-9, 2),
+                                              "unit": "G instructions/s", "frac_of_peak_clock": round(rate / peak, 4)}
                 else:
                     roof["counters_stale"] = True
                     roof["counters_recorded_on"] = rec.get("kernel_source_hash", "unstamped (an earlier build)")
