@@ -69,7 +69,7 @@ constexpr int kMaxChunks = 256;
 
 // Paths between their first and their second ray wait in a ring of the wave in device memory (see
 // "primary rays" in caster_render.hpp): kRingEntries path states of kRingWords 32-bit words, word-major.
-constexpr int kRingEntries = 128;
+constexpr int kRingEntries = 64;
 constexpr int kRingWords = 15;
 constexpr size_t kRingBytesPerWave = (size_t)kRingEntries * kRingWords * sizeof(uint32_t);
 constexpr int kWavesPerBlock = 4;

@@ -1148,11 +1148,10 @@ CDEV void ring_pop(PathRing& r, Slot& s, float4* home)
 // shades the first hit; the survivors join the ring.  A camera ray with a non-finite component is
 // handled as everywhere else (non_finite_rule).
 template <bool TEX, bool EXACT_LDS>
-CDEV void primary_batch(Unit& cur, const TileList& tl, PathRing& ring, const RenderArgs& a, const Cam& cam, const PixelScale& ps,
+CDEV void primary_batch(Slot& sp, Unit& cur, const TileList& tl, const RenderArgs& a, const Cam& cam, const PixelScale& ps,
                         const SceneView& sc, const float4* lds_exact, const AlwaysLds* al, acc_t* wave_acc, unsigned int& rays,
                         int lane)
 {
-    Slot sp;
     sp.thr = mk(1.0f, 1.0f, 1.0f);
     sp.g.s0 = sp.g.s1 = sp.g.draws = 0;
     sp.q = 0; sp.depth = 0;
@@ -1185,6 +1184,62 @@ CDEV void primary_batch(Unit& cur, const TileList& tl, PathRing& ring, const Ren
                         __builtin_isfinite(sp.d.x) && __builtin_isfinite(sp.d.y) && __builtin_isfinite(sp.d.z);
     non_finite_rule(finite, sc.n_sph, closest, best);
     bounce<TEX>(sp, closest, best, sc, cur.tg, wave_acc, a, rays);
+}
+
+// The survivors of a batch go straight into the free slots of the main loop, lane to lane through the
+// LDS crossbar (ds_bpermute), without a trip through device memory; only those that find no free slot
+// wait on the stack.  Survivor number r (in lane order) goes to free slot number r, slot A's free lanes
+// first; `scratch` (64 words of this wave in LDS, idle outside the sphere loop) maps r to the survivor's lane.
+CDEV uint32_t slot_bits(float x) { return __float_as_uint(x); }
+CDEV uint32_t slot_bits(uint32_t x) { return x; }
+CDEV uint32_t slot_bits(int x) { return (uint32_t)x; }
+CDEV void slot_put(float& x, uint32_t u) { x = __uint_as_float(u); }
+CDEV void slot_put(uint32_t& x, uint32_t u) { x = u; }
+CDEV void slot_put(int& x, uint32_t u) { x = (int)u; }
+CDEV uint32_t from_lane(int src, uint32_t x) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)x); }
+
+CDEV void hand_over(Slot& sp, Slot& sa, float4* homeA, Slot& sb, float4* homeB, PathRing& ring, unsigned int* scratch, int lane)
+{
+    const unsigned long long surv = __ballot(sp.alive());
+    if (surv == 0ull) return;
+    const int ns = __popcll(surv);
+    const unsigned long long fa = __ballot(!sa.alive()), fb = __ballot(!sb.alive());
+    const int na = __popcll(fa), nfree = na + __popcll(fb);
+    const int rs = lane_rank(surv);
+    if (sp.alive()) scratch[rs] = (unsigned int)lane;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // LDS instructions of one wave complete in order
+    __builtin_amdgcn_wave_barrier();
+    const int ra = lane_rank(fa), rb = na + lane_rank(fb);
+    const bool takeA = !sa.alive() && ra < ns, takeB = !sb.alive() && rb < ns;
+    const int srcA = takeA ? (int)scratch[ra] : lane;
+    const int srcB = takeB ? (int)scratch[rb] : lane;
+    // every lane takes part in a ds_bpermute; the lanes that take a path keep what they fetched
+#define CASTER_MOVE(field)                                                          \
+    {                                                                               \
+        const uint32_t u = slot_bits(sp.field);                                     \
+        const uint32_t va = from_lane(srcA, u), vb = from_lane(srcB, u);            \
+        if (takeA) slot_put(sa.field, va);                                          \
+        if (takeB) slot_put(sb.field, vb);                                          \
+    }
+    CASTER_MOVE(o.x) CASTER_MOVE(o.y) CASTER_MOVE(o.z) CASTER_MOVE(d.x) CASTER_MOVE(d.y) CASTER_MOVE(d.z)
+#if CASTER_STRICT
+    CASTER_MOVE(aa_)
+#else
+    CASTER_MOVE(tmin_) CASTER_MOVE(tmax_)
+#endif
+    CASTER_MOVE(g.s0) CASTER_MOVE(g.s1) CASTER_MOVE(depth)
+#undef CASTER_MOVE
+    {   // throughput and pixel live in LDS between bounces (cold_out)
+        const uint32_t tx = slot_bits(sp.thr.x), ty = slot_bits(sp.thr.y), tz = slot_bits(sp.thr.z), tq = slot_bits(sp.q);
+        const float4 ca = make_float4(__uint_as_float(from_lane(srcA, tx)), __uint_as_float(from_lane(srcA, ty)),
+                                      __uint_as_float(from_lane(srcA, tz)), __uint_as_float(from_lane(srcA, tq)));
+        const float4 cb = make_float4(__uint_as_float(from_lane(srcB, tx)), __uint_as_float(from_lane(srcB, ty)),
+                                      __uint_as_float(from_lane(srcB, tz)), __uint_as_float(from_lane(srcB, tq)));
+        if (takeA) *homeA = ca;
+        if (takeB) *homeB = cb;
+    }
+    // the survivors without a slot wait on the stack
+    if (rs < nfree) sp.depth = 0;
     ring_push(ring, sp);
     ring.count = __builtin_amdgcn_readfirstlane(ring.count);
 }
@@ -1290,46 +1345,46 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     tl.count = 0;
     tl.all = true;
     unsigned int batches = 0;                   // wave-uniform
+    // 64 words of this wave in LDS that are idle outside the sphere loop (its candidate queue or lists)
+    unsigned int* wave_scratch = MATRIX ? ml.entries : reinterpret_cast<unsigned int*>(s_cand + wave * kListCap * 64);
     float4* homeA = s_cold + wave * 128 + lane;
     float4* homeB = homeA + 64;
     cold_out(sa, homeA);
     cold_out(sb, homeB);
 
     for (;;) {
-        // Supply: the free slots take waiting paths from the ring; before that, as long as the ring
-        // holds fewer than they want, the current unit starts another batch of paths.  A round serves
-        // up to 64 slots (a batch adds up to 64 paths and the ring holds 128); a tile whose paths all
-        // end on the same bounce frees more than that at once, and the rounds repeat.  A unit whose
-        // pool is empty hands its sums to the frame buffer and the wave takes the next one; its paths
-        // still waiting or in flight add their radiance to the frame buffer themselves when they end
-        // (deposit).
+        // Supply: the free slots take the paths that wait on the stack; while slots are still free the
+        // current unit starts another batch of 64 paths, whose survivors go straight into the free
+        // slots (hand_over) -- those that find none wait on the stack, 64 at most.  A unit whose pool is
+        // empty hands its sums to the frame buffer and the wave takes the next one; its paths still
+        // waiting or in flight add their radiance to the frame buffer themselves when they end (deposit).
         {
             const unsigned long long t_refill = tm.now();
             for (;;) {
                 const int need = __popcll(__ballot(!sa.alive())) + __popcll(__ballot(!sb.alive()));
                 if (need == 0) break;
-                const int want = need < 64 ? need : 64;
-                while (ring.count < want) {
-                    if (cur.chunk >= 0 && cur.next >= cur.total) {
-                        flush_unit(cur, wave_acc, a, lane);
-                        cur.chunk = -1;
-                        cur.tg.tw = cur.tg.th = 0;      // no current tile
-                    }
-                    if (cur.chunk < 0) {
-                        if (queue_empty) break;
-                        cur = fetch_unit(a, tiles_x, n_tiles, lane);
-                        queue_empty = cur.chunk < 0;
-                        tm.fetched(!queue_empty, cur.chunk, cur.tg.x0 / kTileW, cur.tg.y0 / kTileH);
-                        if (queue_empty) break;
-                        build_tile_list(tl, cur, a, cam, sc, lane);
-                    }
-                    primary_batch<TEX, kExactLds>(cur, tl, ring, a, cam, ps, sc, s_exact, &s_always, wave_acc, rays, lane);
-                    ++batches;
+                if (ring.count > 0) {                   // waiting paths first
+                    ring_pop(ring, sa, homeA);
+                    ring_pop(ring, sb, homeB);
+                    continue;
                 }
-                if (ring.count == 0) break;             // nothing left to start
-                ring_pop(ring, sa, homeA);
-                ring_pop(ring, sb, homeB);
-                if (need <= 64) break;
+                if (cur.chunk >= 0 && cur.next >= cur.total) {
+                    flush_unit(cur, wave_acc, a, lane);
+                    cur.chunk = -1;
+                    cur.tg.tw = cur.tg.th = 0;      // no current tile
+                }
+                if (cur.chunk < 0) {
+                    if (queue_empty) break;
+                    cur = fetch_unit(a, tiles_x, n_tiles, lane);
+                    queue_empty = cur.chunk < 0;
+                    tm.fetched(!queue_empty, cur.chunk, cur.tg.x0 / kTileW, cur.tg.y0 / kTileH);
+                    if (queue_empty) break;
+                    build_tile_list(tl, cur, a, cam, sc, lane);
+                }
+                Slot sp;
+                primary_batch<TEX, kExactLds>(sp, cur, tl, a, cam, ps, sc, s_exact, &s_always, wave_acc, rays, lane);
+                ++batches;
+                hand_over(sp, sa, homeA, sb, homeB, ring, wave_scratch, lane);
             }
             tm.add(WaveTimers::kRefill, t_refill);
         }

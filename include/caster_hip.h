@@ -195,7 +195,7 @@ int caster_hip_render(caster_hip_ctx* ctx, const caster_camera* cam, int width, 
  * first use or with the context (the per-pixel fixed-point sums of the call, the ray and trip
  * counters, the work queue's head, the rings in which paths wait between their first and their
  * second ray) lives in a static device array of CASTER_HIP_NOALLOC_MAX_PIXELS * 24 + 32 +
- * CASTER_HIP_NOALLOC_MAX_WAVES * 7680 bytes (24 MiB + 30 MiB) that every GPU the library runs on holds
+ * CASTER_HIP_NOALLOC_MAX_WAVES * 3840 bytes (24 MiB + 15 MiB) that every GPU the library runs on holds
  * until the process ends.  Frames of more pixels are refused with CASTER_HIP_ERR_ARG, and so is a GPU
  * that runs more than CASTER_HIP_NOALLOC_MAX_WAVES waves of the render kernel at a time (16 per
  * compute unit: 4 096 on the 256 units of MI355X).  All contexts on one GPU share that GPU's array: calls that
