@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU call's worth of measurement for a round: bench.py, the same under rocprofv3 --kernel-trace --stats,
+# One GPU call of measurement under a tag: bench.py, the same under rocprofv3 --kernel-trace --stats,
 # and the counter passes of tools/pmc.sh for both sphere loops.  usage (on the GPU box): bash tools/profile_round.sh <tag>
 set -e
 tag=$1
