@@ -324,3 +324,26 @@ def test_degenerate_frame_sizes_and_depths(gpu, orc, ca):
                 # only come back, with every path counted at least once
                 f, f_rays, _ = gpu.render_image(cam, w, h, 6, depth, 5, strict=False)
                 assert w * h * 6 <= f_rays <= w * h * 6 * depth and np.all(f[..., 3] == 6)
+
+
+def test_range_of_the_fixed_point_sums(gpu, ca):
+    """What include/caster_hip.h states about the sums of a call: a path's radiance enters the 64-bit
+    fixed-point sum clamped to [0, 1e9] per channel, a NaN counts as 0, and a channel's sum wraps at 2^32.
+    One enclosing emissive sphere, depth 1: every path is one ray that returns the emitter's colour
+    (src/caster.c:467-477), so a pixel's sum is spp times the colour as the sum represents it."""
+    objs = np.zeros(1, ca.OBJECT_DTYPE)
+    objs["g"][0, :4] = (0.0, 0.0, 0.0, 1.0e4)
+    mats = np.zeros(1, ca.MATERIAL_DTYPE)
+    mats["type"][0] = 3                                     # MTYPE_DIFF_LIGHT
+    mats["color0"][0] = (4.0e9, np.nan, 0.75)
+    gpu.upload_scene(ca.FlatScene(objs, mats, []))
+    cam = ca.default_camera(16 / 9)
+    for strict in (True, False):
+        s, rays, _ = gpu.render_image(cam, 32, 18, 3, 1, 5, strict=strict)
+        assert rays == 32 * 18 * 3
+        assert np.all(s[..., 0] == np.float32(3.0e9))      # 4e9 clamped to 1e9, three samples
+        assert np.all(s[..., 1] == 0.0)                    # NaN counts as 0
+        assert np.all(s[..., 2] == np.float32(2.25)) and np.all(s[..., 3] == 3)
+        s, _, _ = gpu.render_image(cam, 32, 18, 5, 1, 5, strict=strict)
+        assert np.all(s[..., 0] == np.float32(5.0e9 - 2.0 ** 32))   # five samples of 1e9 wrap at 2^32
+        assert np.all(s[..., 2] == np.float32(3.75))
