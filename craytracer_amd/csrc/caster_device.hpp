@@ -481,18 +481,20 @@ CDEV float noise_value(const SceneView& sc, V3 p)
     const __attribute__((address_space(3))) uint8_t* px = sc.noise_perm;
     const __attribute__((address_space(3))) uint8_t* py = px + 256;
     const __attribute__((address_space(3))) uint8_t* pz = px + 512;
+    // the six table bytes as 32-bit values, xor-ed three at a time in one instruction each
+    const unsigned int hx[2] = {px[i & 255], px[(i + 1) & 255]};
+    const unsigned int hy[2] = {py[j & 255], py[(j + 1) & 255]};
+    const unsigned int hz[2] = {pz[k & 255], pz[(k + 1) & 255]};
     float accum = 0.0f;
 #pragma unroll
     for (int di = 0; di < 2; di++) {
-        const unsigned int hx = px[(i + di) & 255];
         const float wi = di ? uu : 1.0f - uu;
 #pragma unroll
         for (int dj = 0; dj < 2; dj++) {
-            const unsigned int hxy = hx ^ py[(j + dj) & 255];
             const float wj = dj ? vv : 1.0f - vv;
 #pragma unroll
             for (int dk = 0; dk < 2; dk++) {
-                const __attribute__((address_space(3))) float4* cp = sc.noise_vec + (hxy ^ pz[(k + dk) & 255]);
+                const __attribute__((address_space(3))) float4* cp = sc.noise_vec + xor3(hx[di], hy[dj], hz[dk]);
                 const float cx = cp->x, cy = cp->y, cz = cp->z;
                 const float wk = dk ? ww : 1.0f - ww;
                 const float ox = u - (float)di, oy = v - (float)dj, oz = w - (float)dk;
@@ -517,6 +519,15 @@ CDEV float noise_turb(const SceneView& sc, V3 p)
     return fabsf(accum);
 }
 
+// The marble pattern's brightness at p: what TTYPE_NOISE multiplies the material's colour with.
+CDEV float marble_scale(const SceneView& sc, V3 p, float stripes)
+{
+    return 0.5f * (1.0f + m_sin(stripes * p.z + 10.0f * noise_turb(sc, p)));
+}
+
+// NOISE false: for callers that evaluate the noise textures elsewhere (shade<TEX, true>) and never
+// come here with one that has its tables.
+template <bool NOISE = true>
 CDEV V3 texture_color(const SceneView& sc, const Mat& m, HitRec& rec)           // material.c:65-101
 {
     switch (m.tex) {
@@ -542,8 +553,8 @@ CDEV V3 texture_color(const SceneView& sc, const Mat& m, HitRec& rec)           
         return mk(color_scale * (float)pix[0], color_scale * (float)pix[1], color_scale * (float)pix[2]);
     }
     case 4: { // TTYPE_NOISE (extension): marble
-        if (!sc.has_noise) return mk(0.0f, 0.0f, 0.0f);
-        const float s = 0.5f * (1.0f + m_sin(m.c1[0] * rec.p.z + 10.0f * noise_turb(sc, rec.p)));
+        if (!NOISE || !sc.has_noise) return mk(0.0f, 0.0f, 0.0f);
+        const float s = marble_scale(sc, rec.p, m.c1[0]);
         return mk(m.c0[0] * s, m.c0[1] * s, m.c0[2] * s);
     }
     default:
@@ -569,9 +580,14 @@ CDEV Ray ray_from_cam(const Cam& ci, Rng& g, float u, float v)  // camera.c:32-4
 // radiance `emit` (black for a failed scatter or an unknown tag).
 // TEX false: for scenes whose every texture is a solid colour (TTYPE_COLOR), the instance leaves out
 // the checker, image and noise lookups altogether -- same values, a smaller kernel.
-template <bool TEX = true>
-CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& next, V3& atten, V3& emit)
+// DEFER: a noise texture is not evaluated here.  Its value only scales the path's throughput, which
+// nothing reads before the path's next bounce, so the caller may evaluate it later, for several
+// slots at once: `later` then names the material (-1: nothing left to do), `atten` is 1 and the
+// point to evaluate at is next.o.
+template <bool TEX = true, bool DEFER = false>
+CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& next, V3& atten, V3& emit, int& later)
 {
+    later = -1;
     const Mat m = sc.mats[rec.m];
     emit = mk(0.0f, 0.0f, 0.0f);
     atten = mk(1.0f, 1.0f, 1.0f);
@@ -617,12 +633,23 @@ CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& nex
     default:
         break;
     }
+    if (TEX && DEFER && textured && m.tex == 4 && sc.has_noise && m.type != 3) {
+        later = rec.m;
+        textured = false;
+    }
     if (textured) {
-        const V3 c = TEX ? texture_color(sc, m, rec) : mk(m.c0[0], m.c0[1], m.c0[2]);
+        const V3 c = TEX ? texture_color<!DEFER>(sc, m, rec) : mk(m.c0[0], m.c0[1], m.c0[2]);
         if (m.type == 3) emit = c;
         else atten = c;
     }
     return cont;
+}
+
+template <bool TEX = true>
+CDEV bool shade(const SceneView& sc, Rng& g, const Ray& r, HitRec& rec, Ray& next, V3& atten, V3& emit)
+{
+    int later;
+    return shade<TEX, false>(sc, g, r, rec, next, atten, emit, later);
 }
 
 }  // namespace caster

@@ -944,10 +944,13 @@ CDEV void deposit(int q, V3 radiance, const TileGeom& tg, acc_t* wave_acc, const
 
 // One bounce of a slot's path: shade the hit and either continue the path or
 // end it (adding its radiance to the frame).
-template <bool TEX>
+// DEFER: a noise texture met by a path that goes on is left to the caller (see shade and
+// marble_stage): `later` then holds the material whose colour still has to scale the throughput.
+template <bool TEX, bool DEFER = false>
 CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, const TileGeom& tg, acc_t* wave_acc,
-                 const RenderArgs& a, unsigned int& rays)
+                 const RenderArgs& a, unsigned int& rays, int& later)
 {
+    later = -1;
     const unsigned long long tracing = __ballot(s.alive());
     if (tracing == 0ull) return;
     rays += (unsigned int)__popcll(tracing);     // counted per wave: the same in all lanes
@@ -962,7 +965,7 @@ CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, cons
     if (resolve_hit(s, r, closest, best_sph, sc, rec)) {
         Ray next;
         V3 atten, emit;
-        cont = shade<TEX>(sc, s.g, r, rec, next, atten, emit);
+        cont = shade<TEX, DEFER>(sc, s.g, r, rec, next, atten, emit, later);
         if (cont) {
             s.thr = s.thr * atten;
             set_ray(s, next);
@@ -975,7 +978,16 @@ CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, cons
     if (!cont) {
         deposit(s.q, radiance, tg, wave_acc, a);
         park(s);
+        later = -1;                                  // an ended path's throughput is read no more
     }
+}
+
+template <bool TEX>
+CDEV void bounce(Slot& s, float closest, int best_sph, const SceneView& sc, const TileGeom& tg, acc_t* wave_acc,
+                 const RenderArgs& a, unsigned int& rays)
+{
+    int later;
+    bounce<TEX, false>(s, closest, best_sph, sc, tg, wave_acc, a, rays, later);
 }
 
 // ---- primary rays ----------------------------------------------------------
@@ -1244,6 +1256,69 @@ CDEV void hand_over(Slot& sp, Slot& sa, float4* homeA, Slot& sb, float4* homeB, 
     ring.count = __builtin_amdgcn_readfirstlane(ring.count);
 }
 
+// The noise textures the two slots left for later (bounce<TEX, true>), evaluated for both slots at
+// once.  A marble texel is about a thousand vector instructions whatever the number of lanes that
+// want one, and in either slot only some do: the lanes of slot A without a texel of their own take
+// the texels of slot B (B's r-th texel goes to A's r-th idle lane, through `items`, 64 float4 of this
+// wave in LDS), so that one pass serves both slots whenever the two together want no more than 64; what
+// does not fit is evaluated by its own lane in a second pass.  A texel's value depends on its point
+// and its material alone, not on the lane that evaluates it.  The point is the new ray's origin
+// (the scatter functions start the next ray at the hit point, src/material.c:8,18); the throughput
+// is scaled where it lives between bounces (cold_out).
+CDEV void marble_stage(const SceneView& sc, const Slot& sa, int laterA, float4* homeA, const Slot& sb, int laterB, float4* homeB,
+                       float4* items, int lane)
+{
+    const unsigned long long ma = __ballot(laterA >= 0), mb = __ballot(laterB >= 0);
+    if ((ma | mb) == 0ull) return;
+    const int idle = 64 - __popcll(ma), nb = __popcll(mb);
+    const int moved = nb < idle ? nb : idle;                    // wave-uniform
+    const int rb = lane_rank(mb), ri = lane_rank(~ma);
+    float stripesB = 0.0f;
+    if (laterB >= 0) stripesB = sc.mats[laterB].c1[0];
+    if (laterB >= 0 && rb < moved) items[rb] = make_float4(sb.o.x, sb.o.y, sb.o.z, stripesB);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // LDS instructions of one wave complete in order
+    __builtin_amdgcn_wave_barrier();
+    const bool guest = laterA < 0 && ri < moved;                // this lane evaluates a texel of slot B
+    float scaleA = 1.0f, scaleB = 1.0f;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        V3 p = sa.o;
+        float stripes = 0.0f;
+        bool busy;
+        if (pass == 0) {
+            busy = laterA >= 0 || guest;
+            if (laterA >= 0) stripes = sc.mats[laterA].c1[0];
+            if (guest) { const float4 it = items[ri]; p = mk(it.x, it.y, it.z); stripes = it.w; }
+        } else {
+            busy = laterB >= 0 && rb >= moved;
+            p = sb.o;
+            stripes = stripesB;
+        }
+        float v = 1.0f;
+        if (busy) v = marble_scale(sc, p, stripes);
+        if (pass == 0) {
+            if (laterA >= 0) scaleA = v;
+            if (guest) items[ri].x = v;
+            if (moved == nb) break;                             // nothing left for a second pass
+        } else {
+            if (busy) scaleB = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (laterB >= 0 && rb < moved) scaleB = items[rb].x;
+    if (laterA >= 0) {
+        const Mat m = sc.mats[laterA];
+        const float4 c = *homeA;
+        *homeA = make_float4(c.x * (m.c0[0] * scaleA), c.y * (m.c0[1] * scaleA), c.z * (m.c0[2] * scaleA), c.w);
+    }
+    if (laterB >= 0) {
+        const Mat m = sc.mats[laterB];
+        const float4 c = *homeB;
+        *homeB = make_float4(c.x * (m.c0[0] * scaleB), c.y * (m.c0[1] * scaleB), c.z * (m.c0[2] * scaleB), c.w);
+    }
+}
+
 // Resident blocks per CU = waves per SIMD.  Measured on the 1080p benchmark (strict, ms per frame):
 // 3 (168 VGPRs, no spills) 291, 4 (128 VGPRs) 276, 5 (96 VGPRs) 290, 6 (80 VGPRs) 314.
 #ifndef CASTER_BLOCKS_PER_CU
@@ -1345,7 +1420,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     tl.count = 0;
     tl.all = true;
     unsigned int batches = 0;                   // wave-uniform
-    // 64 words of this wave in LDS that are idle outside the sphere loop (its candidate queue or lists)
+    // 2 KB of this wave in LDS that are idle outside the sphere loop (its candidate queue or lists)
     unsigned int* wave_scratch = MATRIX ? ml.entries : reinterpret_cast<unsigned int*>(s_cand + wave * kListCap * 64);
     float4* homeA = s_cold + wave * 128 + lane;
     float4* homeB = homeA + 64;
@@ -1447,12 +1522,14 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         // Both slots bounce.  The code is the same for the two (one source, two inlined copies), and
         // the tests hold a path to the same bits in either slot, in both arithmetic modes.
         const unsigned long long t_bounce = tm.now();
+        int laterA, laterB;
         cold_in(sa, homeA);
-        bounce<TEX>(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays);
+        bounce<TEX, TEX>(sa, closestA, bestA, sc, cur.tg, wave_acc, a, rays, laterA);
         cold_out(sa, homeA);
         cold_in(sb, homeB);
-        bounce<TEX>(sb, closestB, bestB, sc, cur.tg, wave_acc, a, rays);
+        bounce<TEX, TEX>(sb, closestB, bestB, sc, cur.tg, wave_acc, a, rays, laterB);
         cold_out(sb, homeB);
+        if (TEX) marble_stage(sc, sa, laterA, homeA, sb, laterB, homeB, reinterpret_cast<float4*>(wave_scratch), lane);
         tm.add(WaveTimers::kBounce, t_bounce);
     }
     tm.add(WaveTimers::kTotal, t_begin);
