@@ -347,3 +347,30 @@ def test_range_of_the_fixed_point_sums(gpu, ca):
         s, _, _ = gpu.render_image(cam, 32, 18, 5, 1, 5, strict=strict)
         assert np.all(s[..., 0] == np.float32(5.0e9 - 2.0 ** 32))   # five samples of 1e9 wrap at 2^32
         assert np.all(s[..., 2] == np.float32(3.75))
+
+
+def test_noise_textures_on_a_large_scene(gpu, orc, ca):
+    """Marble materials on 1 500 spheres: the texture instances of the two kernels for scenes of more than
+    512 spheres (exact operands from device memory on the matrix cores; the list through LDS in tiles on the
+    vector unit), whose noise lookups are evaluated for both of a lane's paths at once after the bounces.
+    Strict frames against the CPU restatement, and both loops, both modes, run to run, bit for bit."""
+    fs = ca.scene_stress(1500, 2)
+    mats = fs.materials.copy()
+    marble = np.flatnonzero((mats["type"] == 0) | (mats["type"] == 1))[::2]      # every other lambertian or metal
+    assert len(marble) > 100
+    mats["tex_type"][marble] = 4                                                 # TTYPE_NOISE
+    mats["color1"][marble, 0] = 4.0                                              # stripes per unit of z
+    fs = ca.FlatScene(fs.objects, mats, [], ca.make_noise(3))
+    gpu.upload_scene(fs)
+    w, h, spp, depth, seed = 96, 54, 6, 50, 21
+    cam = ca.default_camera(w / h)
+    g, g_rays, _ = gpu.render_image(cam, w, h, spp, depth, seed, strict=True)
+    o, o_rays = orc.render(orc.Scene.from_flat(fs), cam, w, h, spp, depth, seed)
+    assert g_rays == o_rays
+    _assert_image_close(g, o, spp)
+    for strict in (True, False):
+        m, m_rays, _ = gpu.render_image(cam, 320, 180, 8, depth, seed, strict=strict)
+        v, v_rays, _ = gpu.render_image(cam, 320, 180, 8, depth, seed, strict=strict, vector_loop=True)
+        m2, m2_rays, _ = gpu.render_image(cam, 320, 180, 8, depth, seed, strict=strict)
+        assert m_rays == v_rays == m2_rays and m_rays > 320 * 180 * 8
+        assert np.array_equal(m, v) and np.array_equal(m, m2)
