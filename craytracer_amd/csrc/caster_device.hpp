@@ -39,13 +39,16 @@ __device__ unsigned long long g_caster_wavelog[4096 * 16];  // one record per re
 struct WaveTimers {
     enum Region { kSchedule = 0, kBounce, kRefill, kIntersect, kTotal, kLists, kRegions };
     unsigned long long ticks[kRegions] = {0, 0, 0, 0, 0, 0};   // shader clock ticks per region
+    unsigned long long tail[kRegions] = {0, 0, 0, 0, 0, 0};    // the same after mark()
     unsigned long long trips = 0, units = 0;
     unsigned long long wall0 = 0, wall_last_fetch = 0, wall_empty = 0;  // 100 MHz
     unsigned long long last_unit = 0, trips_at_empty = 0;
     __device__ __forceinline__ unsigned long long now() const { return __builtin_readcyclecounter(); }
     __device__ __forceinline__ void start() { wall0 = wall_clock64(); }
-    __device__ __forceinline__ void add(Region r, unsigned long long t0) { ticks[r] += now() - t0; }
+    __device__ __forceinline__ void add(Region r, unsigned long long t0) { const unsigned long long d = now() - t0; ticks[r] += d; if (marked) tail[r] += d; }
     __device__ __forceinline__ void trip() { ++trips; }
+    unsigned long long marked = 0, trips_at_mark = 0;
+    __device__ __forceinline__ void mark() { marked = 1; trips_at_mark = trips; }       // from here on the regions also add to `tail`
     __device__ __forceinline__ void fetched(bool got, int chunk, int tile_x, int tile_y)
     {
         if (got) { ++units; wall_last_fetch = wall_clock64(); last_unit = (unsigned long long)chunk * 1000000ull + tile_y * 1000 + tile_x; }
@@ -53,7 +56,8 @@ struct WaveTimers {
     }
     // sums into g_caster_stats[16..22] (+ trips into [0] when the event counters are off) and one record
     // per wave: start, end, units, trips, last fetch, last unit, queue-empty time, trips then,
-    // bounce, refill, intersect, lists, total ticks, rays
+    // bounce, refill, intersect, lists, total ticks, rays | trips at mark() << 32, and after mark():
+    // intersect | lists << 32, bounce | refill << 32
     __device__ __forceinline__ void report(int wave_in_block, unsigned int wave_rays)
     {
         if ((threadIdx.x & 63) != 0) return;
@@ -68,7 +72,8 @@ struct WaveTimers {
         wl[0] = wall0; wl[1] = wall1; wl[2] = units; wl[3] = trips;
         wl[4] = wall_last_fetch; wl[5] = last_unit; wl[6] = wall_empty; wl[7] = trips_at_empty;
         wl[8] = ticks[kBounce]; wl[9] = ticks[kRefill]; wl[10] = ticks[kIntersect]; wl[11] = ticks[kLists];
-        wl[12] = ticks[kTotal]; wl[13] = wave_rays;
+        wl[12] = ticks[kTotal]; wl[13] = wave_rays | (trips_at_mark << 32);
+        wl[14] = tail[kIntersect] | (tail[kLists] << 32); wl[15] = tail[kBounce] | (tail[kRefill] << 32);
     }
 };
 #else
@@ -78,6 +83,7 @@ struct WaveTimers {
     __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void add(Region, unsigned long long) {}
     __device__ __forceinline__ void trip() {}
+    __device__ __forceinline__ void mark() {}
     __device__ __forceinline__ void fetched(bool, int, int, int) {}
     __device__ __forceinline__ void report(int, unsigned int) {}
 };

@@ -810,7 +810,7 @@ CDEV void mfma_column(const h8 a0, const h8 a1, const h8 b0, const h8 b1, unsign
 // the scene needs (read ahead).
 template <bool EXACT_LDS>
 CDEV void mfma_block(const uint4 a0, const uint4 a1, int blk, int& base, const SceneView& sc, const float4* lds_exact,
-                     const MfmaRays& mr, MfmaQueue& q, const Slot& sa, const Slot& sb, WaveTimers& tm)
+                     const MfmaRays& mr, MfmaQueue& q, const Slot& sa, const Slot& sb, bool first_column_only, WaveTimers& tm)
 {
     const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
     const int in_tile = blk & (kMfmaTileBlocks - 1);
@@ -820,6 +820,7 @@ CDEV void mfma_block(const uint4 a0, const uint4 a1, int blk, int& base, const S
     }
     const unsigned int block_head = q.head | ((unsigned int)in_tile << 16);
     mfma_column<0>(A0, A1, mr.b00, mr.b01, block_head, q);
+    if (first_column_only) return;          // wave-uniform: the other three column blocks hold no path (gather_paths)
     mfma_column<1>(A0, A1, mr.b10, mr.b11, block_head, q);
     mfma_column<2>(A0, A1, mr.b20, mr.b21, block_head, q);
     mfma_column<3>(A0, A1, mr.b30, mr.b31, block_head, q);
@@ -838,11 +839,47 @@ CDEV void isect_mfma(const SceneView& sc, const float4* lds_exact, int n_blocks,
 #pragma unroll 1
     for (; blk + 1 < n_blocks; blk += 2) {
         const uint4 b0 = tab[(blk + 1) * 128], b1 = tab[(blk + 1) * 128 + 64];
-        mfma_block<EXACT_LDS>(a0, a1, blk, base, sc, lds_exact, mr, q, sa, sb, tm);
+        mfma_block<EXACT_LDS>(a0, a1, blk, base, sc, lds_exact, mr, q, sa, sb, false, tm);
         a0 = tab[(blk + 2) * 128]; a1 = tab[(blk + 2) * 128 + 64];
-        mfma_block<EXACT_LDS>(b0, b1, blk + 1, base, sc, lds_exact, mr, q, sa, sb, tm);
+        mfma_block<EXACT_LDS>(b0, b1, blk + 1, base, sc, lds_exact, mr, q, sa, sb, false, tm);
     }
-    if (blk < n_blocks) mfma_block<EXACT_LDS>(a0, a1, blk, base, sc, lds_exact, mr, q, sa, sb, tm);
+    if (blk < n_blocks) mfma_block<EXACT_LDS>(a0, a1, blk, base, sc, lds_exact, mr, q, sa, sb, false, tm);
+    drain_mfma<EXACT_LDS>(q, sc, lds_exact, base, sa, sb, tm);
+    queue_end(q, closestA, closestB, bestA, bestB);
+}
+
+// The sphere loop of a wave whose paths have been gathered into the first column block
+// (gather_paths).  With a quarter of the work per block the table reads are what such a wave waits
+// for, and the registers of the three idle column blocks are free: four blocks are on their way
+// instead of one.  Reads past the table's last block (it holds one more than the scene needs) are
+// redirected to that block.
+template <bool EXACT_LDS>
+CDEV void isect_mfma_gathered(const SceneView& sc, const float4* lds_exact, int n_blocks, const MfmaRays& mr, MfmaQueue& q,
+                              const Slot& sa, const Slot& sb, float& closestA, float& closestB, int& bestA, int& bestB,
+                              WaveTimers& tm)
+{
+    constexpr int kAhead = 4;
+    queue_begin(q, closestA, closestB, bestA, bestB);
+    const uint4* tab = sc.mfma_tab + (threadIdx.x & 63);
+    uint4 p0[kAhead], p1[kAhead];
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) {
+        const int b = i < n_blocks ? i : n_blocks;
+        p0[i] = tab[b * 128]; p1[i] = tab[b * 128 + 64];
+    }
+    int base = 0;
+#pragma unroll 1
+    for (int blk = 0; blk < n_blocks; blk += kAhead) {
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            if (blk + i < n_blocks) {                       // wave-uniform
+                const uint4 a0 = p0[i], a1 = p1[i];
+                const int b = blk + i + kAhead < n_blocks ? blk + i + kAhead : n_blocks;
+                p0[i] = tab[b * 128]; p1[i] = tab[b * 128 + 64];
+                mfma_block<EXACT_LDS>(a0, a1, blk + i, base, sc, lds_exact, mr, q, sa, sb, true, tm);
+            }
+        }
+    }
     drain_mfma<EXACT_LDS>(q, sc, lds_exact, base, sa, sb, tm);
     queue_end(q, closestA, closestB, bestA, bestB);
 }
@@ -1319,6 +1356,26 @@ CDEV void marble_stage(const SceneView& sc, const Slot& sa, int laterA, float4* 
     }
 }
 
+// The end of a frame: the queue is empty, nothing waits, and what a wave still holds are the few
+// paths that run on towards the depth limit (in the benchmark scene one path in 200 lives past 30
+// rays -- light caught inside a glass sphere -- and those hold a tenth of the slots at any time),
+// scattered over its 128 slots.  A trip costs the same instructions whatever the number of live
+// lanes, so once no more than 32 paths are left they are gathered into the first 32 lanes of slot A
+// -- over the stack, whose pop fills the free lanes in order -- and the sphere loop runs its first
+// column block only from then on: a quarter of the matrix instructions and sign scans, and one
+// bounce instead of two.  Which lane traces a path changes nothing about it.
+CDEV void gather_paths(Slot& sa, float4* homeA, Slot& sb, float4* homeB, PathRing& ring)
+{
+    cold_in(sa, homeA);
+    ring_push(ring, sa);
+    park(sa);
+    cold_in(sb, homeB);
+    ring_push(ring, sb);
+    park(sb);
+    ring.count = __builtin_amdgcn_readfirstlane(ring.count);
+    ring_pop(ring, sa, homeA);
+}
+
 // Resident blocks per CU = waves per SIMD.  Measured on the 1080p benchmark (strict, ms per frame):
 // 3 (168 VGPRs, no spills) 291, 4 (128 VGPRs) 276, 5 (96 VGPRs) 290, 6 (80 VGPRs) 314.
 #ifndef CASTER_BLOCKS_PER_CU
@@ -1408,6 +1465,7 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
     cur.cs = cur.s0 = 0;
     cur.tg.x0 = cur.tg.y0 = cur.tg.tw = cur.tg.th = 0;
     bool queue_empty = false;
+    bool gathered = false;                      // wave-uniform: see gather_paths
 
     // Camera rays are traced apart from the loop (see "primary rays"); paths enter the slots with their
     // second ray, from the ring.
@@ -1464,8 +1522,16 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
             tm.add(WaveTimers::kRefill, t_refill);
         }
 
-        const int live = (sa.alive() || sb.alive()) ? 1 : 0;
         const bool done = queue_empty && cur.chunk < 0 && ring.count == 0;
+        if (MATRIX && done && !gathered) {
+            const int left = __popcll(__ballot(sa.alive())) + __popcll(__ballot(sb.alive()));
+            if (left <= 32) {
+                if (left > 0) gather_paths(sa, homeA, sb, homeB, ring);
+                gathered = true;
+                tm.mark();
+            }
+        }
+        const int live = (sa.alive() || sb.alive()) ? 1 : 0;
         if (TILED) {
             // the tile loop below has block-wide barriers: all four waves leave together
             if (__syncthreads_or((live || !done) ? 1 : 0) == 0) break;
@@ -1497,7 +1563,8 @@ void CASTER_NAME(render_kernel_)(RenderArgs a)
         test_always(&s_always, a.scene.n_always, sa, sb, closestA, closestB, bestA, bestB);
         if (MATRIX) {
             const MfmaRays mr = pack_rays_mfma(sa, sb, ref, a.scene.mfma_scale);
-            isect_mfma<KIND == kLoopMatrix>(sc, s_exact, a.scene.mfma_blocks, mr, ml, sa, sb, closestA, closestB, bestA, bestB, tm);
+            if (gathered) isect_mfma_gathered<KIND == kLoopMatrix>(sc, s_exact, a.scene.mfma_blocks, mr, ml, sa, sb, closestA, closestB, bestA, bestB, tm);
+            else isect_mfma<KIND == kLoopMatrix>(sc, s_exact, a.scene.mfma_blocks, mr, ml, sa, sb, closestA, closestB, bestA, bestB, tm);
             non_finite_rule(mr.finiteA, sc.n_sph, closestA, bestA);
             non_finite_rule(mr.finiteB, sc.n_sph, closestB, bestB);
         } else {

@@ -65,7 +65,11 @@ for mode in ("strict", "fast"):
               (i, en[i], (wl[i, 4] - t0) * 1e-5, wl[i, 5], (wl[i, 6] - t0) * 1e-5, wl[i, 3] - wl[i, 7], wl[i, 3]))
         print("      per trip: bounce %.0f refill %.0f isect %.0f (queue %.0f) total %.0f ticks; rays %d, utilisation %.3f" %
               (wl[i, 8] / wl[i, 3], wl[i, 9] / wl[i, 3], wl[i, 10] / wl[i, 3], wl[i, 11] / wl[i, 3], wl[i, 12] / wl[i, 3],
-               wl[i, 13], wl[i, 13] / (128.0 * wl[i, 3])))
+               wl[i, 13] & 0xFFFFFFFF, (wl[i, 13] & 0xFFFFFFFF) / (128.0 * wl[i, 3])))
+        nt = max(wl[i, 3] - (wl[i, 13] >> 32), 1)
+        print("      the last %d trips (paths gathered), per trip:" % nt, end="")
+        print(" isect %.0f (queue %.0f) bounce %.0f refill %.0f ticks" %
+              ((wl[i, 14] & 0xFFFFFFFF) / nt, (wl[i, 14] >> 32) / nt, (wl[i, 15] & 0xFFFFFFFF) / nt, (wl[i, 15] >> 32) / nt))
     print("  shader clock while busy %.0f MHz; mean wave busy time %.2f ms of %.2f ms" %
           (100.0 * total / out[22], out[22] / 4096.0 * 1e-5, ms))
     for i, name in enumerate(("schedule", "bounce", "refill", "intersect (incl. queue)", "total", "queue")):
