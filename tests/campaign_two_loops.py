@@ -4,7 +4,12 @@ sphere filter on the matrix cores.  Random scenes -- sphere counts 34 to 4000, e
 cameras inside and outside the cloud -- rendered in both arithmetic modes with the filter on the
 matrix cores and on the vector unit, and once more with every camera ray meeting every sphere
 instead of its tile's list (lenses from a pinhole to half the cloud across, focus planes before, in
-and behind the cloud); all frames of a case must agree bit for bit."""
+and behind the cloud); all frames of a case must agree bit for bit.
+usage: python tests/campaign_two_loops.py [--noise] [--cases N]
+--noise: every other diffuse or metal material of a scene carries the marble texture (the texture
+instances of the kernels, whose noise lookups are evaluated for both of a lane's paths at once).
+Every render ends with the waves' last paths gathered into one column block of the matrix loop,
+with or without textures."""
 import sys
 import os
 
@@ -30,15 +35,26 @@ def random_scene(rng, base):
     objs["g"][big, :3] += centre.astype(np.float32)
     objs["g"][big, 3] *= np.float32(max(extent / 50.0, 1e-3))
     objs["g"][big, 1] -= np.float32(extent)                      # ground below the cloud
-    return ca.FlatScene(objs, fs.materials, []), centre, extent, n
+    mats, noise = fs.materials, None
+    if NOISE:
+        mats = mats.copy()
+        marble = np.flatnonzero((mats["type"] == 0) | (mats["type"] == 1))[::2]
+        mats["tex_type"][marble] = 4                                            # TTYPE_NOISE
+        mats["color1"][marble, 0] = np.float32(rng.uniform(0.5, 8.0) / max(extent, 1e-6))   # stripes per scene unit
+        noise = ca.make_noise(int(rng.integers(1, 1000)))
+    return ca.FlatScene(objs, mats, [], noise), centre, extent, n
+
+
+NOISE = "--noise" in sys.argv
+CASES = int(sys.argv[sys.argv.index("--cases") + 1]) if "--cases" in sys.argv else 40
 
 
 def main():
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(2025 if NOISE else 2024)
     gpu = ca.CasterHip(0)
     w, h, spp = 320, 180, 8
     bad = 0
-    for case in range(40):
+    for case in range(CASES):
         fs, centre, extent, n = random_scene(rng, case)
         gpu.upload_scene(fs)
         eye = centre + rng.normal(size=3) * extent * float(rng.choice([0.3, 1.5, 4.0]))
